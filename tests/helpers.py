@@ -1,0 +1,57 @@
+"""Shared test helpers (inputs for the BASELINE configs, golden loading)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def preprocess_demo(u8):
+    """demo.ipynb cell 4 (reference): percentile-1/99 clip over non-zero pixels, min-max,
+    (x-0.5)/0.5, rot90(k=-1)."""
+    img = np.asarray(u8)
+    low, high = np.percentile(img[img > 0], [1, 99])
+    img = np.clip(img, low, high)
+    img = (img - img.min()) / (img.max() - img.min())
+    img = (img - 0.5) / 0.5
+    t = torch.tensor(img, dtype=torch.float32)[None, None]
+    return torch.rot90(t, k=-1, dims=(2, 3)).contiguous()
+
+
+def demo_conds():
+    g = load_golden('demo_inputs_u8.npz')
+    return [preprocess_demo(g[n].numpy()) for n in ('flair', 't2', 't1')]
+
+
+def sampler_inputs(cfg, B, seed_x=42):
+    """x_init and the per-step (z, noise) stream exactly as tests/golden/make_golden.py drew them."""
+    H = cfg.image_size
+    g = torch.Generator().manual_seed(seed_x)
+    x_init = torch.randn(B, 1, H, H, generator=g)
+    st = torch.get_rng_state()
+    torch.manual_seed(seed_x + 1)
+    zs, noises = [], []
+    for _ in range(cfg.num_timesteps):
+        zs.append(torch.randn(B, cfg.nz))
+        noises.append(torch.randn(B, 1, H, H))
+    torch.set_rng_state(st)
+    return x_init, zs, noises
+
+
+SMALL_CFGS = {
+    's32': dict(image_size=32, num_channels_dae=32, ch_mult=[1, 2, 4], attn_resolutions=(16,)),
+    's32na': dict(image_size=32, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(), num_res_blocks=1),
+    's16t8': dict(image_size=16, num_channels_dae=16, ch_mult=[1, 1, 2], attn_resolutions=(4,),
+                  num_timesteps=8, nz=50, z_emb_dim=64, n_mlp=2),
+}
+
+
+def small_conds(cfg, B=2):
+    g = torch.Generator().manual_seed(101)
+    return [torch.tanh(torch.randn(B, 1, cfg.image_size, cfg.image_size, generator=g)) for _ in range(3)]
