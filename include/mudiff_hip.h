@@ -1,0 +1,140 @@
+/*
+ * mudiff_hip.h - C ABI of libmudiff_hip.so: the MI355X (gfx950) kernels behind MU-Diff's
+ * dual-generator reverse-diffusion sampling path.
+ *
+ * The reference has no FFI for this path except two pybind functions (utils/op/upfirdn2d.cpp:20-31,
+ * utils/op/fused_bias_act.cpp:18-28); everything else is torch ops called from Python.  The entry
+ * points below are what a binding for the path binds instead; each one names the reference code it
+ * replaces (paths relative to the reference checkout).  Plain pointers and sizes only - no torch
+ * types.  All pointers are DEVICE pointers unless a parameter says "host".  Every call enqueues on
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream), allocates nothing and never
+ * synchronises, so a caller may capture any sequence of calls into a hipGraph.
+ *
+ * Activation layout: NHWC fp32, described as a *view* (ptr, B, H, W, C, ld): element (b,y,x,c) lives
+ * at ptr[((b*H + y)*W + x)*ld + c] with ld >= C, so a channel slice of a wider tensor (the
+ * concatenations of the U-Net) is a view and never a copy.  With C == 1 (the generator inputs and
+ * outputs) NHWC and the reference's NCHW coincide.
+ *
+ * Return value: 0 on success, a MUD_ERR_* code otherwise; mud_last_error() gives the text.
+ */
+#ifndef MUDIFF_HIP_H
+#define MUDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUD_OK 0
+#define MUD_ERR_ARG 1      /* bad shape / alignment / null pointer                 */
+#define MUD_ERR_LAUNCH 2   /* hipGetLastError() after a launch reported a failure  */
+#define MUD_ERR_UNSUPPORTED 3
+
+#define MUD_ACT_NONE 0
+#define MUD_ACT_SIGMOID 1
+#define MUD_ACT_TANH 2
+#define MUD_ACT_SILU 3
+
+#define MUD_PRO_NONE 0         /* A operand used as stored                                   */
+#define MUD_PRO_AFFINE 1       /* a[b,c]*x + s[b,c]            (GroupNorm, AttnBlockpp)      */
+#define MUD_PRO_AFFINE_SILU 2  /* silu(a[b,c]*x + s[b,c])      (AdaGN + SiLU of the ResBlock) */
+
+int mud_version(void);
+const char* mud_last_error(void);
+/* bytes of device workspace the calls below need at most for a given problem: see each call */
+
+/* ---- L3: Gaussian posterior / forward diffusion (engine/test.py:126-177, engine/train.py:256-281)
+ * out = 0.5*((c1[t]*x01 + c2[t]*xt) + (c1[t]*x02 + c2[t]*xt)) + (t != 0) * std[t] * noise
+ * x02 == NULL gives the single-predictor sample_posterior (engine/test.py:126-147).
+ * std[t] = exp(0.5*posterior_log_variance_clipped[t]) is a host-made table (engine/test.py:143,173).
+ * The arithmetic is un-contracted fp32 mul/add in the reference's order: results are bit-identical
+ * to the PyTorch-CPU path.  t is int64 [B]; indices are clamped to [0, ntab). */
+int mud_posterior_sample(const float* x01, const float* x02, const float* xt, const float* noise,
+                         const int64_t* t, const float* coef1, const float* coef2, const float* std_tab,
+                         int ntab, float* out, int B, int64_t per_sample, void* stream);
+/* out = a_tab[t+toff]*x + s_tab[t+toff]*noise   (q_sample: a_s_cum/sigmas_cum, toff 0;
+ * second half of q_sample_pairs: a_s/sigmas, toff 1).  engine/train.py:256-281. */
+int mud_q_sample(const float* x, const float* noise, const int64_t* t, int toff, const float* a_tab,
+                 const float* s_tab, int ntab, float* out, int B, int64_t per_sample, void* stream);
+
+/* ---- embeddings and the small dense path (backbones/layers.py:465-479, dense_layer.py:67-71,
+ *      ncsnpp_generator_adagn_feat.py:44-49,271-277,301-305; layerspp.py:42,277) */
+int mud_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_positions, void* stream);
+int mud_pixel_norm(const float* z, float* out, int B, int K, void* stream);
+/* out[b, n] = act_out( sum_k W[n,k] * act_in(in[b,k]) + bias[n] ),  W row-major [N,K] (nn.Linear). */
+int mud_dense(const float* in, int ldi, const float* W, const float* bias, float* out, int ldo,
+              int B, int K, int N, int act_in, int act_out, void* stream);
+
+/* ---- GroupNorm statistics -> per-(sample, channel) scale/shift for a consumer's prologue
+ *      (torch native_group_norm as used by backbones/layerspp.py:37-65,103, eps 1e-6, biased var).
+ * scale[b,c] = gamma[b,c] * rstd[b,g(c)],  shift[b,c] = beta[b,c] - mean[b,g(c)] * scale[b,c]
+ * gamma/beta: NULL (=1/0), per channel (g_bstride 0) or per sample (g_bstride = row stride).
+ * ws: device workspace of mud_gn_ws_bytes(B, HW, C, G) bytes. */
+int64_t mud_gn_ws_bytes(int B, int64_t HW, int C, int G);
+int mud_gn_scale_shift(const float* x, int B, int64_t HW, int C, int ld, int G, float eps,
+                       const float* gamma, const float* beta, int64_t g_bstride,
+                       float* scale, float* shift, int ld_ss, float* mean_rstd /* [B,G,2] or NULL */,
+                       void* ws, void* stream);
+/* out[b,c] = mean over pixels (nn.AdaptiveAvgPool2d(1), layerspp.py:473,491). ws as above with G=C. */
+int mud_channel_mean(const float* x, int B, int64_t HW, int C, int ld, float* out, int ldo, void* ws, void* stream);
+
+/* ---- convolutions (torch F.conv2d call sites: layers.py:104-128, layerspp.py:275-285,399-408,
+ *      ncsnpp_generator_adagn_feat.py:267,620-631; NIN einsum layers.py:502-505; the attention
+ *      contractions layerspp.py:118-122) */
+typedef struct mud_conv_args {
+  const float* x;  int B, H, W, Cin, ldx;        /* input view                                      */
+  const void* w;   int64_t w_bstride;            /* weights (format depends on the call); bytes     */
+                                                 /* between per-sample weight sets, 0 = shared       */
+  int ks, stride, pad;                           /* square kernel                                    */
+  const float* pro_scale; const float* pro_shift; int pro_ld; int pro_mode;   /* [B,Cin] each        */
+  const float* bias;                             /* [Cout] or NULL                                   */
+  const float* bias2; int bias2_ld;              /* [B,Cout] or NULL  (Dense_0(act(temb)))           */
+  const float* res; int ldr;                     /* residual view [B,Ho,Wo,Cout] or NULL             */
+  float out_scale; int act;                      /* out = act((acc+bias+bias2+res)*out_scale)        */
+  float* out; int Cout, ldo;                     /* output view [B,Ho,Wo,Cout]                       */
+} mud_conv_args;
+
+/* Exact fp32 direct convolution (FMA chain per output), any ks/stride/pad/Cin/Cout.
+ * w: fp32 [ks][ks][Cin][Cout].  Used for Cin==1 heads, Cout==1 tail and strided convs. */
+int mud_conv2d_direct(const mud_conv_args* a, void* stream);
+
+/* Implicit-GEMM convolution on the matrix cores, ks in {1,3}, stride 1, pad ks/2.
+ * fp32 operands are split on the fly into bf16 hi+lo and multiplied as hi*hi + hi*lo + lo*hi with
+ * fp32 accumulation (v_mfma_f32_32x32x16_bf16 x3): ~2^-17 relative error per product.
+ * w: packed by mud_pack_weights().  Requires Cin % 4 == 0, ldx % 4 == 0, 16-byte aligned x.
+ * For ks == 1 the (H, W) plane is treated as one flat axis of H*W positions (plain GEMM). */
+int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout);
+/* src element (tap, ci, co) = src[tap*s_tap + ci*s_ci + co*s_co] (+ b*src_bstride elements).
+ *   OIHW conv weight:  s_tap=1, s_ci=ks*ks, s_co=Cin*ks*ks;   NIN W[in,out]: s_ci=Cout, s_co=1;
+ *   K^T of attention: rows of K as "co": s_ci=1, s_co=ldk;   V: s_ci=ldv, s_co=1.               */
+int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride,
+                     int ks, int Cin, int Cout, int nbatch, void* dst, void* stream);
+int mud_conv2d_mfma(const mud_conv_args* a, void* stream);
+
+/* ---- FIR resampling (utils/op/upfirdn2d.cpp:20-31 + upfirdn2d_kernel.cu:109-209; python front
+ *      ends backbones/up_or_down_sampling.py:149-262).
+ * Plane form = the reference's pybind op: input [planes, H, W] (its [major, in_h, in_w, minor=1]),
+ * kernel fp32 [kh, kw] on the device, same argument meaning as upfirdn2d(...). */
+int mud_upfirdn2d(const float* in, int64_t planes, int H, int W, const float* kernel, int kh, int kw,
+                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                  float* out, void* stream);
+/* NHWC form used inside the generators: same filter maths on a view, optionally producing in ONE
+ * pass both FIR(prologue(x)) (out_h) and FIR(x) (out_x) as ResnetBlockBigGANpp_Adagn needs
+ * (layerspp.py:293-308).  kernel: host pointer to kh*kw floats (<= 64). Either output may be NULL. */
+int mud_fir_nhwc(const float* x, int B, int H, int W, int C, int ldx, const float* kernel_host, int kh, int kw,
+                 int up, int down, int pad0, int pad1,
+                 const float* pro_scale, const float* pro_shift, int pro_ld, int pro_mode,
+                 float* out_h, int ldh, float* out_x, int ldxo, void* stream);
+
+/* ---- attention pieces (layerspp.py:118-122) and the G2 feature fusion (…feat.py:769-788) */
+int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* stream);          /* in place */
+int mud_mul(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t npix, int C, void* stream);
+/* out = g*att + (1-g)*other */
+int mud_gate_mix(const float* g, int ldg, const float* att, int lda, const float* other, int ldb,
+                 float* out, int ldo, int64_t npix, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,390 @@
+"""The two mutually-learned NCSN++ denoising generators of MU-Diff, MI355X-native.
+
+`NCSNpp(config)` (G1, contrast-specific) and `NCSNpp_adaptive(config)` (G2, contrast-aware; consumes
+G1's prediction as pseudo-target) keep the reference's constructor/forward signatures and state_dict
+(reference backbones/ncsnpp_generator_adagn_feat.py:53-447 and :451-905; key layout in SURVEY.md
+section 8b), so checkpoints and `engine/test.py` / `demo.ipynb` work unchanged.  `forward` never runs
+torch arithmetic: it schedules hand-written gfx950 kernels (libmudiff_hip.so) on NHWC views -
+
+  * embeddings: pixel-norm + z-MLP, sinusoidal t-embedding + MLP, then ALL per-block Dense_0 and AdaGN
+    `style` Linears of the network as two batched weight-streaming GEMVs (they depend only on z and t);
+  * trunk: fused ResBlocks / attention (backbones/layerspp.py), U-Net concatenations as channel-slice
+    views of shared buffers (the producer writes straight into its slot; nothing is copied);
+  * tail: GroupNorm+SiLU prologue, 3x3 conv to one channel, tanh epilogue in one direct kernel.
+
+Supported: the default configuration family (resblock_type='biggan', fir=True, progressive='none',
+progressive_input='residual', embedding_type='positional', conditional=True) with any nf / ch_mult /
+num_res_blocks / attn_resolutions / image size.  Other variants raise NotImplementedError (SURVEY.md
+section 8 row f4).  GPU tensors only; ambient autocast is ignored (fp32 in, fp32 out).
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mudiff_hip import ops
+from mudiff_hip.ops import ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, INV_SQRT2, PRO_AFFINE_SILU, View
+
+from . import dense_layer, layers, layerspp, utils
+
+ResnetBlockBigGAN = layerspp.ResnetBlockBigGANpp_Adagn
+ResnetBlock_Feat = layerspp.ConvFeatBlock
+ResnetBlock_Adapt_Feat = layerspp.ConvBlock
+ResnetBlock_Feat_GAP = layerspp.ConvBlock_GAP
+conv3x3 = layerspp.conv3x3
+conv1x1 = layerspp.conv1x1
+default_initializer = layers.default_init
+dense = dense_layer.dense
+
+
+class PixelNorm(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, input):
+        return ops.pixel_norm(input)
+
+
+def _check_config(config):
+    problems = []
+    if config.resblock_type.lower() != 'biggan':
+        problems.append(f"resblock_type={config.resblock_type!r}")
+    if config.progressive.lower() != 'none':
+        problems.append(f"progressive={config.progressive!r}")
+    if config.progressive_input.lower() != 'residual':
+        problems.append(f"progressive_input={config.progressive_input!r}")
+    if config.embedding_type.lower() != 'positional':
+        problems.append(f"embedding_type={config.embedding_type!r}")
+    if not (config.conditional and config.fir and config.resamp_with_conv):
+        problems.append('conditional/fir/resamp_with_conv must all be True')
+    if problems:
+        raise NotImplementedError('alternate NCSN++ config not built yet (SURVEY.md section 8 f4): ' + ', '.join(problems))
+
+
+class _NCSNppBase(nn.Module, layerspp._Prepared):
+    ADAPTIVE = False
+
+    def __init__(self, config):
+        super().__init__()
+        _check_config(config)
+        self.config = config
+        self.not_use_tanh = config.not_use_tanh
+        self.act = act = nn.SiLU()
+        self.z_emb_dim = z_emb_dim = config.z_emb_dim
+        self.nf = nf = config.num_channels_dae
+        ch_mult = list(config.ch_mult)
+        self.num_res_blocks = num_res_blocks = config.num_res_blocks
+        self.attn_resolutions = attn_resolutions = tuple(int(a) for a in config.attn_resolutions)
+        dropout = config.dropout
+        self.num_resolutions = num_resolutions = len(ch_mult)
+        self.all_resolutions = all_resolutions = [config.image_size // (2 ** i) for i in range(num_resolutions)]
+        self.conditional = config.conditional
+        fir, fir_kernel = config.fir, config.fir_kernel
+        self.skip_rescale = skip_rescale = config.skip_rescale
+        self.resblock_type = config.resblock_type.lower()
+        self.progressive = config.progressive.lower()
+        self.progressive_input = config.progressive_input.lower()
+        self.embedding_type = config.embedding_type.lower()
+        init_scale = 0.
+        channels = config.num_channels
+
+        ResnetBlock = functools.partial(ResnetBlockBigGAN, act=act, dropout=dropout, fir=fir, fir_kernel=fir_kernel,
+                                        init_scale=init_scale, skip_rescale=skip_rescale, temb_dim=nf * 4, zemb_dim=z_emb_dim)
+        AttnBlock = functools.partial(layerspp.AttnBlockpp, init_scale=init_scale, skip_rescale=skip_rescale)
+        pyramid_downsample = functools.partial(layerspp.Downsample, fir=fir, fir_kernel=fir_kernel, with_conv=True)
+
+        modules = [nn.Linear(nf, nf * 4), nn.Linear(nf * 4, nf * 4)]
+        for lin in modules:
+            lin.weight.data = default_initializer()(lin.weight.shape)
+            nn.init.zeros_(lin.bias)
+
+        self._plan = plan = []            # (kind, module index, ...) walked by forward
+
+        def add(kind, mod, **kw):
+            modules.append(mod)
+            plan.append(dict(kind=kind, idx=len(modules) - 1, **kw))
+
+        if not self.ADAPTIVE:
+            for _ in range(4):
+                add('feat', ResnetBlock_Feat(act=act, in_ch=channels, out_ch=nf))
+        else:
+            add('gap', ResnetBlock_Feat_GAP(act=act, in_ch=channels, out_ch=nf))
+            add('feat', ResnetBlock_Feat(act=act, in_ch=channels, out_ch=nf))
+            for _ in range(3):
+                add('ada', ResnetBlock_Adapt_Feat(act=act, in_ch=channels, out_ch=nf))
+
+        hs_c = [nf * 4]
+        in_ch = nf * 4
+        input_pyramid_ch = channels
+        for i_level in range(num_resolutions):
+            for _ in range(num_res_blocks):
+                out_ch = nf * ch_mult[i_level]
+                add('res', ResnetBlock(in_ch=in_ch, out_ch=out_ch), stage='down')
+                in_ch = out_ch
+                if all_resolutions[i_level] in attn_resolutions:
+                    add('attn', AttnBlock(channels=in_ch), stage='down')
+                hs_c.append(in_ch)
+            if i_level != num_resolutions - 1:
+                add('res', ResnetBlock(down=True, in_ch=in_ch), stage='downsample')
+                add('pyr', pyramid_downsample(in_ch=input_pyramid_ch, out_ch=in_ch))
+                input_pyramid_ch = in_ch
+                hs_c.append(in_ch)
+        self._hs_channels = list(hs_c)
+        in_ch = hs_c[-1]
+        add('res', ResnetBlock(in_ch=in_ch), stage='mid')
+        add('attn', AttnBlock(channels=in_ch), stage='mid')
+        add('res', ResnetBlock(in_ch=in_ch), stage='mid')
+
+        if self.ADAPTIVE:   # registered BEFORE all_modules, like the reference (state_dict order)
+            self.feat_weight_c1 = conv3x3(nf, nf)
+            self.feat_weight_c2 = conv3x3(nf, nf)
+            self.feat_weight_c3 = conv3x3(nf, nf)
+            self.feat_att1_c12 = conv3x3(3 * nf, nf)
+            self.feat_att2_c12 = conv3x3(3 * nf, nf)
+            self.feat_att1_c23 = conv3x3(3 * nf, nf)
+            self.feat_att2_c23 = conv3x3(3 * nf, nf)
+            self.feat_att1_c31 = conv3x3(3 * nf, nf)
+            self.feat_att2_c31 = conv3x3(3 * nf, nf)
+
+        for i_level in reversed(range(num_resolutions)):
+            for _ in range(num_res_blocks + 1):
+                out_ch = nf * ch_mult[i_level]
+                add('res', ResnetBlock(in_ch=in_ch + hs_c.pop(), out_ch=out_ch), stage='up')
+                in_ch = out_ch
+            if all_resolutions[i_level] in attn_resolutions:
+                add('attn', AttnBlock(channels=in_ch), stage='up')
+            if i_level != 0:
+                add('res', ResnetBlock(in_ch=in_ch, up=True), stage='upsample')
+        assert not hs_c
+        add('gn', nn.GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6))
+        add('conv', conv3x3(in_ch, channels, init_scale=init_scale))
+
+        self.all_modules = nn.ModuleList(modules)
+
+        mapping_layers = [PixelNorm(), dense(config.nz, z_emb_dim), self.act]
+        for _ in range(config.n_mlp):
+            mapping_layers.append(dense(z_emb_dim, z_emb_dim))
+            mapping_layers.append(self.act)
+        self.z_transform = nn.Sequential(*mapping_layers)
+
+    # ------------------------------------------------------------------------------------------
+    def _prepare(self):
+        """Batched small-dense weights: every GroupNorm_{0,1}.style of the ResBlocks in one matrix
+        (input zemb), every Dense_0 in another (input silu(temb))."""
+        mods = self.all_modules
+        style_w, style_b, dense_w, dense_b = [], [], [], []
+        offs = {}
+        so = do = 0
+        for e in self._plan:
+            if e['kind'] != 'res':
+                continue
+            m = mods[e['idx']]
+            o0, o1 = so, so + 2 * m.in_ch
+            so = o1 + 2 * m.out_ch
+            offs[e['idx']] = (o0, o1, so, do)
+            do += m.out_ch
+            style_w += [m.GroupNorm_0.style.weight, m.GroupNorm_1.style.weight]
+            style_b += [m.GroupNorm_0.style.bias, m.GroupNorm_1.style.bias]
+            dense_w.append(m.Dense_0.weight)
+            dense_b.append(m.Dense_0.bias)
+        p = dict(offs=offs,
+                 style_w=torch.cat(style_w, 0).contiguous(), style_b=torch.cat(style_b, 0).contiguous(),
+                 dense_w=torch.cat(dense_w, 0).contiguous(), dense_b=torch.cat(dense_b, 0).contiguous())
+        tail_conv = mods[self._plan[-1]['idx']]
+        p['tail'] = layerspp.ConvParam(tail_conv)
+        if self.ADAPTIVE:
+            gates = [self.feat_att1_c12, self.feat_att2_c12, self.feat_att1_c23, self.feat_att2_c23, self.feat_att1_c31,
+                     self.feat_att2_c31]
+            wg = torch.cat([g.weight for g in gates], 0).contiguous()          # [6nf, 3nf, 3, 3]
+            p['gates_w'] = ops.pack_conv_weight(wg) if layerspp.use_mfma(wg.shape[1], wg.shape[0]) else ops.direct_weight(wg)
+            p['gates_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
+            p['gates_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
+            p['fw'] = [layerspp.ConvParam(c) for c in (self.feat_weight_c1, self.feat_weight_c2, self.feat_weight_c3)]
+            ada = [mods[e['idx']] for e in self._plan if e['kind'] == 'ada']
+            p['ada_w'] = torch.cat([m.group_norm.style.weight for m in ada], 0).contiguous()
+            p['ada_b'] = torch.cat([m.group_norm.style.bias for m in ada], 0).contiguous()
+        return p
+
+    def _embeddings(self, time_cond, z):
+        mods = self.all_modules
+        h = ops.pixel_norm(z.float())
+        for layer in self.z_transform:
+            if isinstance(layer, nn.Linear):
+                h = ops.dense(h, layer.weight.detach(), layer.bias.detach(), act_out=ACT_SILU)
+        zemb = h
+        temb = layers.get_timestep_embedding(time_cond, self.nf)
+        temb = ops.dense(temb, mods[0].weight.detach(), mods[0].bias.detach())
+        temb = ops.dense(temb, mods[1].weight.detach(), mods[1].bias.detach(), act_in=ACT_SILU)
+        return temb, zemb
+
+    def _check_inputs(self, x, *conds):
+        ops.require_gpu(x, *conds)
+        B, C, H, W = x.shape
+        if C != self.config.num_channels or C != 1:
+            raise NotImplementedError(f'the MI355X build handles single-channel slices (num_channels=1), got {C}')
+        for c in conds:
+            if tuple(c.shape) != (B, C, H, W):
+                raise ValueError(f'condition shape {tuple(c.shape)} does not match x {tuple(x.shape)}')
+        if H % (2 ** (self.num_resolutions - 1)) or W % (2 ** (self.num_resolutions - 1)):
+            raise ValueError(f'H, W must be divisible by {2 ** (self.num_resolutions - 1)}')
+        return B, H, W
+
+    def _prep_image(self, t):
+        v = View.from_nchw(t.detach())
+        if not self.config.centered:   # data in [0,1] (reference :309-311); rare path, plain torch affine
+            v = View((2 * v.base - 1.).contiguous(), v.B, v.H, v.W, v.C)
+        return v
+
+    def _make_buffers(self, B, H, W, dev):
+        """U-Net concatenation buffers.  Skip k (the k-th tensor pushed on the down path) is popped by
+        up-block j = n_skips-1-k, whose input is cat([h, skip_k]) (reference :383).  Each up-block gets
+        ONE buffer [B,H,W,Ch+Cs]; the producer of h and the producer of skip_k write straight into
+        their channel slots, so no concatenation is ever copied."""
+        mods = self.all_modules
+        trunk = [e for e in self._plan if e['kind'] in ('res', 'attn', 'pyr')]
+        sizes = [(H, W)]
+        hh, ww = H, W
+        for e in trunk:
+            if e['kind'] == 'res' and e['stage'] == 'down':
+                sizes.append((hh, ww))
+            elif e['kind'] == 'res' and e['stage'] == 'downsample':
+                hh, ww = hh // 2, ww // 2
+                sizes.append((hh, ww))
+        n_skips = len(self._hs_channels)
+        assert len(sizes) == n_skips
+        up_blocks = [e for e in trunk if e['kind'] == 'res' and e['stage'] == 'up']
+        assert len(up_blocks) == n_skips
+        bufs = []
+        for j, e in enumerate(up_blocks):
+            m = mods[e['idx']]
+            cs = self._hs_channels[n_skips - 1 - j]
+            sh_, sw_ = sizes[n_skips - 1 - j]
+            bufs.append((View.empty(B, sh_, sw_, m.in_ch, dev), m.in_ch - cs, cs))
+        return trunk, bufs
+
+    def _trunk(self, p, trunk, bufs, x_img: View, temb, zemb):
+        """Down / mid / up path (reference :335-447, identical for both generators).  The head feature
+        map (skip 0) has already been written into bufs[-1]'s skip slot by the caller."""
+        mods = self.all_modules
+        n_skips = len(bufs)
+        styles = ops.dense(zemb, p['style_w'], p['style_b'])                       # [B, sum 2C]
+        tb_all = ops.dense(temb, p['dense_w'], p['dense_b'], act_in=ACT_SILU)      # [B, sum Cout]
+        rescale = INV_SQRT2 if self.skip_rescale else 1.0
+
+        def res(e, x, out=None):
+            o0, o1, o2, d0 = p['offs'][e['idx']]
+            m = mods[e['idx']]
+            return m.run(x, styles[:, o0:o1], styles[:, o1:o2], tb_all[:, d0:d0 + m.out_ch], out=out)
+
+        def skip_slot(k):
+            buf, ch, cs = bufs[n_skips - 1 - k]
+            return buf.slice(ch, cs)
+
+        def h_slot(j):
+            buf, ch, cs = bufs[j]
+            return buf.slice(0, ch)
+
+        def nxt_is(i, kind, stage):
+            return i + 1 < len(trunk) and trunk[i + 1]['kind'] == kind and trunk[i + 1]['stage'] == stage
+
+        skips = [skip_slot(0)]
+        pyr = x_img
+        h = skips[0]
+        up_j = 0
+        i = 0
+        while i < len(trunk):
+            e = trunk[i]
+            kind, stage = e['kind'], e.get('stage')
+            if kind == 'res' and stage == 'down':
+                if nxt_is(i, 'attn', 'down'):
+                    h = res(e, skips[-1])
+                    i += 1
+                    h = mods[trunk[i]['idx']].run(h, out=skip_slot(len(skips)))
+                else:
+                    h = res(e, skips[-1], out=skip_slot(len(skips)))
+                skips.append(h)
+            elif kind == 'res' and stage == 'downsample':
+                hd = res(e, skips[-1])
+                i += 1
+                # input pyramid: FIR + strided conv, epilogue fuses (+bias, + hd) / sqrt2 (reference :359-366)
+                h = mods[trunk[i]['idx']].run(pyr, res=hd, out_scale=rescale, out=skip_slot(len(skips)))
+                pyr = h
+                skips.append(h)
+            elif kind == 'res' and stage == 'mid':
+                h = res(e, h, out=None if nxt_is(i, 'attn', 'mid') else h_slot(0))
+            elif kind == 'attn':
+                h = mods[e['idx']].run(h)
+            elif kind == 'res' and stage == 'up':
+                buf, ch, cs = bufs[up_j]
+                assert h.base is buf.base and skips[-1].base is buf.base, 'concat slot bookkeeping broke'
+                skips.pop()
+                up_j += 1
+                h = res(e, buf, out=h_slot(up_j) if nxt_is(i, 'res', 'up') else None)
+            elif kind == 'res' and stage == 'upsample':
+                h = res(e, h, out=h_slot(up_j))
+            else:
+                raise AssertionError(e)
+            i += 1
+        assert not skips and up_j == n_skips
+        # ---- tail: GroupNorm(affine) + SiLU prologue, conv3x3 -> 1 channel, tanh epilogue
+        gn = mods[self._plan[-2]['idx']]
+        sc, sh = ops.gn_scale_shift(h, gn.num_groups, gn.weight.detach(), gn.bias.detach())
+        out = p['tail'](h, pro=(sc, sh, PRO_AFFINE_SILU), act=ACT_NONE if self.not_use_tanh else ACT_TANH)
+        return out.to_nchw()
+
+
+@utils.register_model(name='ncsnpp')
+class NCSNpp(_NCSNppBase):
+    """G1 - contrast-specific NCSN++ generator (reference :53-447)."""
+    ADAPTIVE = False
+
+    def forward(self, x, cond1, cond2, cond3, time_cond, z):
+        with torch.no_grad(), torch.autocast('cuda', enabled=False):
+            B, H, W = self._check_inputs(x, cond1, cond2, cond3)
+            p = self.prepared()
+            mods = self.all_modules
+            temb, zemb = self._embeddings(time_cond, z)
+            xv = self._prep_image(x)
+            imgs = [xv] + [View.from_nchw(c.detach()) for c in (cond1, cond2, cond3)]
+            nf = self.nf
+            trunk, bufs = self._make_buffers(B, H, W, xv.device)
+            hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
+            for j, (e, img) in enumerate(zip([e for e in self._plan if e['kind'] == 'feat'], imgs)):
+                mods[e['idx']].run(img, out=hs0.slice(j * nf, nf))
+            return self._trunk(p, trunk, bufs, xv, temb, zemb)
+
+
+@utils.register_model(name='ncsnpp_adaptive')
+class NCSNpp_adaptive(_NCSNppBase):
+    """G2 - contrast-aware NCSN++ generator (reference :451-905): the three condition feature maps are
+    AdaGN-modulated by a style vector pooled from the pseudo-target (G1's prediction) and fused pairwise
+    through sigmoid gates before entering the shared trunk."""
+    ADAPTIVE = True
+
+    def forward(self, x, cond1, cond2, cond3, time_cond, z, pseudo_target):
+        with torch.no_grad(), torch.autocast('cuda', enabled=False):
+            B, H, W = self._check_inputs(x, cond1, cond2, cond3, pseudo_target)
+            p = self.prepared()
+            mods = self.all_modules
+            temb, zemb = self._embeddings(time_cond, z)
+            xv = self._prep_image(x)
+            nf, dev = self.nf, xv.device
+            e_gap = next(e for e in self._plan if e['kind'] == 'gap')
+            e_feat = next(e for e in self._plan if e['kind'] == 'feat')
+            e_ada = [e for e in self._plan if e['kind'] == 'ada']
+            pseudo_weight = mods[e_gap['idx']].run(View.from_nchw(pseudo_target.detach().contiguous()))   # [B,256]
+            trunk, bufs = self._make_buffers(B, H, W, dev)
+            hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
+            mods[e_feat['idx']].run(xv, out=hs0.slice(0, nf))
+            ada_styles = ops.dense(pseudo_weight, p['ada_w'], p['ada_b'])                                  # [B, 3*2nf]
+            cat = View.empty(B, H, W, 3 * nf, dev)
+            for j, (e, c) in enumerate(zip(e_ada, (cond1, cond2, cond3))):
+                mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf))
+            # six sigmoid gate convs share their input: one conv with 6*nf output channels (reference :769-776)
+            gates = ops.conv(cat, p['gates_w'], 3, 6 * nf, mfma=p['gates_mfma'], bias=p['gates_b'], act=ACT_SIGMOID)
+            for j, (a, b_) in enumerate(((0, 1), (1, 2), (2, 0))):      # (c1,c2), (c2,c3), (c3,c1)  (reference :778-788)
+                g1, g2 = gates.slice(2 * j * nf, nf), gates.slice((2 * j + 1) * nf, nf)
+                att = p['fw'][j](ops.mul(g1, cat.slice(a * nf, nf)))
+                ops.gate_mix(g2, att, cat.slice(b_ * nf, nf), hs0.slice((j + 1) * nf, nf))
+            return self._trunk(p, trunk, bufs, xv, temb, zemb)

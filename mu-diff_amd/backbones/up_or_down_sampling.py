@@ -1,0 +1,106 @@
+"""StyleGAN2-style FIR resampling front ends (reference backbones/up_or_down_sampling.py) over the
+gfx950 up-FIR-down kernel.  Public functions keep the reference's names, arguments and NCHW tensors."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mudiff_hip import ops
+from mudiff_hip.ops import View
+from utils.op import upfirdn2d
+
+
+def _setup_kernel(k):
+    k = np.asarray(k, dtype=np.float32)
+    if k.ndim == 1:
+        k = np.outer(k, k)
+    k /= np.sum(k)
+    assert k.ndim == 2 and k.shape[0] == k.shape[1]
+    return k
+
+
+def fir_params(mode, k=None, factor=2, gain=1, conv_k=3):
+    """(kernel2d, up, down, (pad0, pad1)) for 'up' (upsample_2d:200-229), 'down' (downsample_2d:232-262)
+    and 'conv_down' (the FIR stage of conv_downsample_2d:149-183)."""
+    if k is None:
+        k = [1] * factor
+    if mode == 'up':
+        kk = _setup_kernel(k) * (gain * (factor ** 2))
+        p = kk.shape[0] - factor
+        return kk, factor, 1, ((p + 1) // 2 + factor - 1, p // 2)
+    kk = _setup_kernel(k) * gain
+    if mode == 'down':
+        p = kk.shape[0] - factor
+        return kk, 1, factor, ((p + 1) // 2, p // 2)
+    if mode == 'conv_down':
+        p = (kk.shape[0] - factor) + (conv_k - 1)
+        return kk, 1, 1, ((p + 1) // 2, p // 2)
+    raise ValueError(mode)
+
+
+def upsample_2d(x, k=None, factor=2, gain=1):
+    kk, up, down, pad = fir_params('up', k, factor, gain)
+    return upfirdn2d(x, torch.tensor(kk, device=x.device, dtype=x.dtype), up=up, pad=pad)
+
+
+def downsample_2d(x, k=None, factor=2, gain=1):
+    kk, up, down, pad = fir_params('down', k, factor, gain)
+    return upfirdn2d(x, torch.tensor(kk, device=x.device, dtype=x.dtype), down=down, pad=pad)
+
+
+def conv_downsample_2d(x, w, k=None, factor=2, gain=1):
+    """FIR (padded once) then the strided convolution with OIHW weights `w`, no bias."""
+    kk, _, _, pad = fir_params('conv_down', k, factor, gain, conv_k=w.shape[-1])
+    xf = upfirdn2d(x, torch.tensor(kk, device=x.device, dtype=x.dtype), pad=pad)
+    out = ops.conv(View.from_nchw(xf), ops.direct_weight(w), w.shape[-1], w.shape[0], mfma=False, stride=factor, pad=0)
+    return out.to_nchw()
+
+
+def naive_upsample_2d(x, factor=2):
+    raise NotImplementedError('fir=False resamplers are an alternate config (SURVEY.md section 8 f4), not built yet')
+
+
+def naive_downsample_2d(x, factor=2):
+    raise NotImplementedError('fir=False resamplers are an alternate config (SURVEY.md section 8 f4), not built yet')
+
+
+class Conv2d(nn.Module):
+    """Conv2d with optional FIR down-sampling (reference up_or_down_sampling.py:28-61).  `up=True` is
+    dead code in the reference (its upsample_conv_2d raises on torch tensors)."""
+
+    def __init__(self, in_ch, out_ch, kernel, up=False, down=False, resample_kernel=(1, 3, 3, 1), use_bias=True, kernel_init=None):
+        super().__init__()
+        assert not (up and down)
+        assert kernel >= 1 and kernel % 2 == 1
+        self.weight = nn.Parameter(torch.zeros(out_ch, in_ch, kernel, kernel))
+        if kernel_init is not None:
+            self.weight.data = kernel_init(self.weight.data.shape)
+        if use_bias:
+            self.bias = nn.Parameter(torch.zeros(out_ch))
+        self.up, self.down, self.resample_kernel, self.kernel, self.use_bias = up, down, resample_kernel, kernel, use_bias
+        self._prep = None
+
+    def _weights(self):
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._prep is None or self._prep[0] != key:
+            self._prep = (key, ops.direct_weight(self.weight))
+        return self._prep[1]
+
+    def run(self, x: View, res: View = None, out_scale=1.0, out: View = None):
+        """NHWC entry used by the generators; residual add and rescale fused into the conv epilogue."""
+        if self.up:
+            raise NotImplementedError('Conv2d(up=True) is unreachable in the reference (upsample_conv_2d raises)')
+        bias = self.bias.detach() if self.use_bias else None
+        if not self.down:
+            return ops.conv(x, self._weights(), self.kernel, self.weight.shape[0], mfma=False, bias=bias, res=res, out_scale=out_scale, out=out)
+        kk, up, down, pad = fir_params('conv_down', self.resample_kernel, conv_k=self.kernel)
+        if x.C % 4 == 0:
+            xf, _ = ops.fir_nhwc(x, kk, up, down, pad)
+        else:   # single-channel image pyramid: NHWC == planes
+            assert x.C == 1 and x.ld == 1
+            t = upfirdn2d(x.base.reshape(x.B, 1, x.H, x.W), torch.tensor(kk, device=x.device), pad=pad)
+            xf = View(t, x.B, t.shape[2], t.shape[3], 1)
+        return ops.conv(xf, self._weights(), self.kernel, self.weight.shape[0], mfma=False, stride=2, pad=0, bias=bias, res=res,
+                        out_scale=out_scale, out=out)
+
+    def forward(self, x):
+        return self.run(View.from_nchw(x)).to_nchw()

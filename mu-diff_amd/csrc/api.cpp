@@ -1,0 +1,15 @@
+// Error plumbing shared by every translation unit of libmudiff_hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/mudiff_hip.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void mud_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mud_last_error(void) { return g_err; }
+extern "C" int mud_version(void) { return 100; }

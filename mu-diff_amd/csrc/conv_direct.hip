@@ -1,0 +1,96 @@
+// Exact-fp32 direct convolution on NHWC views (one fmaf chain per output, like ATen's reference
+// arithmetic up to summation order).  It serves the shapes that are bandwidth- rather than
+// FLOP-bound and that the MFMA implicit GEMM does not cover:
+//   * Cin == 1 head convolutions (1 -> nf at full resolution: a pure 256 B/pixel store stream),
+//   * the Cout == 1 output convolution (GroupNorm+SiLU prologue, tanh epilogue fused),
+//   * the stride-2 convolution of the input-pyramid Downsample (after the FIR),
+// and acts as the exact fallback for any other shape.  One thread owns one output pixel and VO
+// consecutive output channels; the VO-wide weight rows are wave-uniform loads served by L1/L2.
+#include "mud_common.h"
+
+template <int VO, int VI>
+__global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, int Wo, int co_groups) {
+  const int64_t total = (int64_t)a.B * Ho * Wo * co_groups;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % co_groups);
+    int64_t p = idx / co_groups;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int co = cg * VO;
+    float acc[VO];
+#pragma unroll
+    for (int j = 0; j < VO; ++j) acc[j] = 0.f;
+    const float* wb = (const float*)((const char*)a.w + (int64_t)b * a.w_bstride);
+    for (int ky = 0; ky < a.ks; ++ky) {
+      const int iy = oy * a.stride - a.pad + ky;
+      if (iy < 0 || iy >= a.H) continue;
+      for (int kx = 0; kx < a.ks; ++kx) {
+        const int ix = ox * a.stride - a.pad + kx;
+        if (ix < 0 || ix >= a.W) continue;
+        const float* xp = a.x + (((int64_t)b * a.H + iy) * a.W + ix) * a.ldx;
+        const float* wp = wb + ((int64_t)(ky * a.ks + kx) * a.Cin) * a.Cout + co;
+        for (int ci = 0; ci < a.Cin; ci += VI) {
+          float xv[VI];
+          if (VI == 4) *(f32x4*)xv = *(const f32x4*)(xp + ci);
+          else xv[0] = xp[ci];
+#pragma unroll
+          for (int u = 0; u < VI; ++u) {
+            float v = xv[u];
+            if (a.pro_mode != MUD_PRO_NONE)
+              v = mud_prologue(v, a.pro_scale[(int64_t)b * a.pro_ld + ci + u], a.pro_shift[(int64_t)b * a.pro_ld + ci + u], a.pro_mode);
+            const float* w = wp + (int64_t)(ci + u) * a.Cout;
+            if (VO == 4) {
+              const f32x4 wv = *(const f32x4*)w;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, wv[j], acc[j]);
+            } else {
+              acc[0] = fmaf(v, w[0], acc[0]);
+            }
+          }
+        }
+      }
+    }
+    const int64_t opix = ((int64_t)b * Ho + oy) * Wo + ox;
+#pragma unroll
+    for (int j = 0; j < VO; ++j) {
+      float v = acc[j];
+      if (a.bias) v += a.bias[co + j];
+      if (a.bias2) v += a.bias2[(int64_t)b * a.bias2_ld + co + j];
+      if (a.res) v += a.res[opix * a.ldr + co + j];
+      acc[j] = mud_act(v * a.out_scale, a.act);
+    }
+    float* op = a.out + opix * a.ldo + co;
+    if (VO == 4) *(f32x4*)op = *(f32x4*)acc;
+    else op[0] = acc[0];
+  }
+}
+
+extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
+  MUD_REQUIRE(ap, "mud_conv2d_direct: null args");
+  const mud_conv_args a = *ap;
+  MUD_REQUIRE(a.x && a.w && a.out, "mud_conv2d_direct: null pointer");
+  MUD_REQUIRE(a.B >= 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0 && a.ks >= 1 && a.stride >= 1 && a.pad >= 0,
+              "mud_conv2d_direct: bad sizes");
+  MUD_REQUIRE(a.ldx >= a.Cin && a.ldo >= a.Cout, "mud_conv2d_direct: ld smaller than C");
+  MUD_REQUIRE(a.pro_mode == MUD_PRO_NONE || (a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin), "mud_conv2d_direct: prologue arrays missing");
+  MUD_REQUIRE(!a.res || a.ldr >= a.Cout, "mud_conv2d_direct: bad residual view");
+  const int Ho = (a.H + 2 * a.pad - a.ks) / a.stride + 1, Wo = (a.W + 2 * a.pad - a.ks) / a.stride + 1;
+  MUD_REQUIRE(Ho > 0 && Wo > 0, "mud_conv2d_direct: empty output");
+  if (a.B == 0) return MUD_OK;
+  const bool vo4 = a.Cout % 4 == 0 && a.ldo % 4 == 0 && mud_aligned16(a.out) && mud_aligned16(a.w) && (a.w_bstride % 16 == 0);
+  const bool vi4 = a.Cin % 4 == 0 && a.ldx % 4 == 0 && mud_aligned16(a.x);
+  const int co_groups = vo4 ? a.Cout / 4 : a.Cout;
+  const int64_t total = (int64_t)a.B * Ho * Wo * co_groups;
+  int64_t blocks = mud_cdiv(total, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((int)blocks), block(256);
+  if (vo4 && vi4) hipLaunchKernelGGL((k_conv_direct<4, 4>), grid, block, 0, s, a, Ho, Wo, co_groups);
+  else if (vo4) hipLaunchKernelGGL((k_conv_direct<4, 1>), grid, block, 0, s, a, Ho, Wo, co_groups);
+  else if (vi4) hipLaunchKernelGGL((k_conv_direct<1, 4>), grid, block, 0, s, a, Ho, Wo, co_groups);
+  else hipLaunchKernelGGL((k_conv_direct<1, 1>), grid, block, 0, s, a, Ho, Wo, co_groups);
+  MUD_CHECK_LAUNCH("mud_conv2d_direct");
+  return MUD_OK;
+}

@@ -1,0 +1,231 @@
+// HBM-bound elementwise kernels of the sampling path: Gaussian posterior step, q_sample,
+// embeddings, row softmax and the G2 gated feature fusion.  16 B per lane everywhere
+// (coalesced 1 KiB per wave instruction); grids capped at ~8 blocks/CU and grid-strided.
+#include "mud_common.h"
+
+static inline int mud_grid_1d(int64_t work_items, int block) {
+  int64_t g = mud_cdiv(work_items, block);
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// posterior: reference order of operations, no FMA contraction (engine/test.py:150-177)
+// ------------------------------------------------------------------------------------------------
+template <bool DUAL, bool VEC>
+__global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ x01, const float* __restrict__ x02,
+                                                   const float* __restrict__ xt, const float* __restrict__ noise,
+                                                   const int64_t* __restrict__ t, const float* __restrict__ c1t,
+                                                   const float* __restrict__ c2t, const float* __restrict__ sdt,
+                                                   int ntab, float* __restrict__ out, int64_t per_sample) {
+  const int b = blockIdx.y;
+  int64_t ti = t[b];
+  ti = ti < 0 ? 0 : (ti >= ntab ? ntab - 1 : ti);
+  const float c1 = c1t[ti], c2 = c2t[ti];
+  const float sd = (ti == 0) ? 0.0f : sdt[ti];   // nonzero_mask * exp(0.5*log_var)
+  const int64_t base = (int64_t)b * per_sample;
+  constexpr int V = VEC ? 4 : 1;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < per_sample;
+       i += (int64_t)gridDim.x * blockDim.x * V) {
+    float a[V], bb[V], x[V], n[V], o[V];
+    if (VEC) {
+      *(f32x4*)a = *(const f32x4*)(x01 + base + i);
+      if (DUAL) *(f32x4*)bb = *(const f32x4*)(x02 + base + i);
+      *(f32x4*)x = *(const f32x4*)(xt + base + i);
+      *(f32x4*)n = *(const f32x4*)(noise + base + i);
+    } else {
+      a[0] = x01[base + i];
+      if (DUAL) bb[0] = x02[base + i];
+      x[0] = xt[base + i];
+      n[0] = noise[base + i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float cx = __fmul_rn(c2, x[j]);
+      float mean = __fadd_rn(__fmul_rn(c1, a[j]), cx);
+      if (DUAL) {
+        const float m2 = __fadd_rn(__fmul_rn(c1, bb[j]), cx);
+        mean = __fmul_rn(__fadd_rn(mean, m2), 0.5f);   // (mean1 + mean2) / 2, exact halving
+      }
+      o[j] = __fadd_rn(mean, __fmul_rn(sd, n[j]));
+    }
+    if (VEC) *(f32x4*)(out + base + i) = *(f32x4*)o;
+    else out[base + i] = o[0];
+  }
+}
+
+extern "C" int mud_posterior_sample(const float* x01, const float* x02, const float* xt, const float* noise,
+                                    const int64_t* t, const float* coef1, const float* coef2, const float* std_tab,
+                                    int ntab, float* out, int B, int64_t per_sample, void* stream) {
+  MUD_REQUIRE(x01 && xt && noise && t && coef1 && coef2 && std_tab && out, "mud_posterior_sample: null pointer");
+  MUD_REQUIRE(B >= 0 && per_sample >= 0 && ntab > 0, "mud_posterior_sample: bad sizes B=%d per_sample=%lld ntab=%d", B,
+              (long long)per_sample, ntab);
+  if (B == 0 || per_sample == 0) return MUD_OK;
+  MUD_REQUIRE(B <= 65535, "mud_posterior_sample: B=%d exceeds 65535", B);
+  const bool vec = (per_sample % 4 == 0) && mud_aligned16(x01) && mud_aligned16(xt) && mud_aligned16(noise) &&
+                   mud_aligned16(out) && (!x02 || mud_aligned16(x02));
+  dim3 grid(mud_grid_1d(per_sample / (vec ? 4 : 1), 256), B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(D, V) hipLaunchKernelGGL((k_posterior<D, V>), grid, block, 0, s, x01, x02, xt, noise, t, coef1, coef2, std_tab, ntab, out, per_sample)
+  if (x02) { if (vec) LAUNCH(true, true); else LAUNCH(true, false); }
+  else     { if (vec) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  MUD_CHECK_LAUNCH("mud_posterior_sample");
+  return MUD_OK;
+}
+
+__global__ __launch_bounds__(256) void k_q_sample(const float* __restrict__ x, const float* __restrict__ noise,
+                                                  const int64_t* __restrict__ t, int toff, const float* __restrict__ at,
+                                                  const float* __restrict__ st, int ntab, float* __restrict__ out,
+                                                  int64_t per_sample) {
+  const int b = blockIdx.y;
+  int64_t ti = t[b] + toff;
+  ti = ti < 0 ? 0 : (ti >= ntab ? ntab - 1 : ti);
+  const float a = at[ti], sg = st[ti];
+  const int64_t base = (int64_t)b * per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * blockDim.x)
+    out[base + i] = __fadd_rn(__fmul_rn(a, x[base + i]), __fmul_rn(sg, noise[base + i]));
+}
+
+extern "C" int mud_q_sample(const float* x, const float* noise, const int64_t* t, int toff, const float* a_tab,
+                            const float* s_tab, int ntab, float* out, int B, int64_t per_sample, void* stream) {
+  MUD_REQUIRE(x && noise && t && a_tab && s_tab && out, "mud_q_sample: null pointer");
+  MUD_REQUIRE(B >= 0 && per_sample >= 0 && ntab > 0 && B <= 65535, "mud_q_sample: bad sizes");
+  if (B == 0 || per_sample == 0) return MUD_OK;
+  dim3 grid(mud_grid_1d(per_sample, 256), B), block(256);
+  hipLaunchKernelGGL(k_q_sample, grid, block, 0, (hipStream_t)stream, x, noise, t, toff, a_tab, s_tab, ntab, out, per_sample);
+  MUD_CHECK_LAUNCH("mud_q_sample");
+  return MUD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings
+// ------------------------------------------------------------------------------------------------
+__global__ void k_timestep_embedding(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_log_over) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i % dim;
+  float v = 0.0f;
+  if (j < 2 * half) {
+    const int k = j < half ? j : j - half;
+    const float freq = expf((float)k * neg_log_over);
+    const float arg = (float)t[b] * freq;
+    v = j < half ? sinf(arg) : cosf(arg);
+  }
+  out[i] = v;   // odd dim: last column zero-padded (layers.py:476-477)
+}
+
+extern "C" int mud_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_positions, void* stream) {
+  MUD_REQUIRE(t && out && B >= 0 && dim >= 4, "mud_timestep_embedding: bad args");
+  if (B == 0) return MUD_OK;
+  const int half = dim / 2;
+  const float neg = -(float)(log((double)max_positions) / (double)(half - 1));
+  hipLaunchKernelGGL(k_timestep_embedding, dim3(mud_cdiv((int64_t)B * dim, 256)), dim3(256), 0, (hipStream_t)stream, t, out, B, dim, neg);
+  MUD_CHECK_LAUNCH("mud_timestep_embedding");
+  return MUD_OK;
+}
+
+__global__ __launch_bounds__(64) void k_pixel_norm(const float* __restrict__ z, float* __restrict__ out, int K) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float ss = 0.f;
+  for (int k = lane; k < K; k += 64) { const float v = z[(int64_t)b * K + k]; ss += v * v; }
+  ss = mud_wave_sum(ss);
+  const float d = sqrtf(ss / (float)K + 1e-8f);
+  for (int k = lane; k < K; k += 64) out[(int64_t)b * K + k] = z[(int64_t)b * K + k] / d;
+}
+
+extern "C" int mud_pixel_norm(const float* z, float* out, int B, int K, void* stream) {
+  MUD_REQUIRE(z && out && B >= 0 && K > 0, "mud_pixel_norm: bad args");
+  if (B == 0) return MUD_OK;
+  hipLaunchKernelGGL(k_pixel_norm, dim3(B), dim3(64), 0, (hipStream_t)stream, z, out, K);
+  MUD_CHECK_LAUNCH("mud_pixel_norm");
+  return MUD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax, in place: one 256-thread block per row, three L2-resident sweeps
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ s, int64_t rows, int n, int ld) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    float* row = s + r * (int64_t)ld;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, row[i]);
+    m = mud_wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float e = expf(row[i] - m); row[i] = e; sum += e; }
+    sum = mud_wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    for (int i = threadIdx.x; i < n; i += 256) row[i] *= inv;
+  }
+}
+
+extern "C" int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* stream) {
+  MUD_REQUIRE(s && rows >= 0 && n > 0 && ld >= n, "mud_softmax_rows: bad args");
+  if (rows == 0) return MUD_OK;
+  const int grid = (int)(rows < 256 * 32 ? rows : 256 * 32);
+  hipLaunchKernelGGL(k_softmax_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, rows, n, ld);
+  MUD_CHECK_LAUNCH("mud_softmax_rows");
+  return MUD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// G2 feature fusion elementwise pieces (ncsnpp_generator_adagn_feat.py:778-788)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>  // 0: a*b   1: g*att + (1-g)*other
+__global__ __launch_bounds__(256) void k_ew3(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                             const float* __restrict__ c, int ldc, float* __restrict__ out, int ldo,
+                                             int64_t npix, int C4) {
+  const int64_t total = npix * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / C4;
+    const int q = (int)(i % C4) * 4;
+    const f32x4 va = *(const f32x4*)(a + p * lda + q);
+    const f32x4 vb = *(const f32x4*)(b + p * ldb + q);
+    f32x4 o;
+    if (MODE == 0) o = va * vb;
+    else {
+      const f32x4 vc = *(const f32x4*)(c + p * ldc + q);
+      o = va * vb + (1.0f - va) * vc;
+    }
+    *(f32x4*)(out + p * ldo + q) = o;
+  }
+}
+
+static int ew_check(const char* name, const void* a, int lda, const void* b, int ldb, const void* o, int ldo, int C) {
+  MUD_REQUIRE(a && b && o, "%s: null pointer", name);
+  MUD_REQUIRE(C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0 && mud_aligned16(a) && mud_aligned16(b) && mud_aligned16(o),
+              "%s: needs C, ld multiples of 4 and 16-byte aligned views", name);
+  return MUD_OK;
+}
+
+extern "C" int mud_mul(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t npix, int C, void* stream) {
+  if (int e = ew_check("mud_mul", a, lda, b, ldb, out, ldo, C)) return e;
+  if (npix == 0) return MUD_OK;
+  hipLaunchKernelGGL((k_ew3<0>), dim3(mud_grid_1d(npix * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     (const float*)nullptr, 0, out, ldo, npix, C / 4);
+  MUD_CHECK_LAUNCH("mud_mul");
+  return MUD_OK;
+}
+
+extern "C" int mud_gate_mix(const float* g, int ldg, const float* att, int lda, const float* other, int ldb, float* out,
+                            int ldo, int64_t npix, int C, void* stream) {
+  if (int e = ew_check("mud_gate_mix", g, ldg, att, lda, out, ldo, C)) return e;
+  MUD_REQUIRE(other && ldb % 4 == 0 && mud_aligned16(other), "mud_gate_mix: bad `other` view");
+  if (npix == 0) return MUD_OK;
+  hipLaunchKernelGGL((k_ew3<1>), dim3(mud_grid_1d(npix * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, att, lda,
+                     other, ldb, out, ldo, npix, C / 4);
+  MUD_CHECK_LAUNCH("mud_gate_mix");
+  return MUD_OK;
+}

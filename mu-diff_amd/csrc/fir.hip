@@ -1,0 +1,140 @@
+// Up-FIR-down resampling (StyleGAN2 upfirdn2d) for gfx950.
+//
+// Maths (utils/op/upfirdn2d.py:201-242 of the reference): zero-stuff by `up`, pad by (pad0, pad1)
+// (negative = crop), TRUE convolution with the kh x kw kernel, keep every `down`-th sample:
+//   out[oy,ox] = sum_{m,n} k[kh-1-m][kw-1-n] * U[oy*down + m - pad0][ox*down + n - pad0],
+//   U[Y][X] = in[Y/up][X/up] if Y%up==0 and X%up==0 and inside, else 0.
+// Only the taps that land on real samples are visited (polyphase): for the 4x4 [1,3,3,1] filter that
+// is 4 of 16 taps per output when up == 2.
+//
+// Two forms: planes [P,H,W] (the reference's pybind op boundary; W is the coalesced axis) and NHWC
+// views (inside the generators; C is the coalesced axis, 16 B per lane, optional AdaGN+SiLU prologue
+// and a second, un-normalised output produced from the same loads).
+#include "mud_common.h"
+
+#define FIR_MAX_TAPS 64
+struct FirKernel { float k[FIR_MAX_TAPS]; };
+
+__global__ __launch_bounds__(256) void k_upfirdn2d_planes(const float* __restrict__ in, int64_t planes, int H, int W,
+                                                          const float* __restrict__ kern, int kh, int kw, int up_x, int up_y,
+                                                          int down_x, int down_y, int pad_x0, int pad_y0, int Ho, int Wo,
+                                                          float* __restrict__ out) {
+  __shared__ float sk[FIR_MAX_TAPS];
+  for (int i = threadIdx.x; i < kh * kw; i += 256) sk[i] = kern[i];
+  __syncthreads();
+  const int64_t total = planes * Ho * Wo;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wo);
+    const int64_t r = idx / Wo;
+    const int oy = (int)(r % Ho);
+    const int64_t pl = r / Ho;
+    const float* ip = in + pl * H * W;
+    float acc = 0.f;
+    for (int m = 0; m < kh; ++m) {
+      const int Y = oy * down_y + m - pad_y0;
+      if (Y < 0 || Y % up_y) continue;
+      const int iy = Y / up_y;
+      if (iy >= H) continue;
+      for (int n = 0; n < kw; ++n) {
+        const int X = ox * down_x + n - pad_x0;
+        if (X < 0 || X % up_x) continue;
+        const int ix = X / up_x;
+        if (ix >= W) continue;
+        acc = fmaf(sk[(kh - 1 - m) * kw + (kw - 1 - n)], ip[(int64_t)iy * W + ix], acc);
+      }
+    }
+    out[idx] = acc;
+  }
+}
+
+extern "C" int mud_upfirdn2d(const float* in, int64_t planes, int H, int W, const float* kernel, int kh, int kw, int up_x,
+                             int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* out,
+                             void* stream) {
+  MUD_REQUIRE(in && kernel && out, "mud_upfirdn2d: null pointer");
+  MUD_REQUIRE(planes >= 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && kh * kw <= FIR_MAX_TAPS, "mud_upfirdn2d: bad sizes (kernel up to %d taps)", FIR_MAX_TAPS);
+  MUD_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "mud_upfirdn2d: up/down must be >= 1");
+  const int Ho = (H * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+  const int Wo = (W * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  MUD_REQUIRE(Ho > 0 && Wo > 0 && (H * up_y + pad_y0 + pad_y1 - kh) >= 0 && (W * up_x + pad_x0 + pad_x1 - kw) >= 0, "mud_upfirdn2d: empty output");
+  if (planes == 0) return MUD_OK;
+  int64_t blocks = mud_cdiv(planes * Ho * Wo, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(k_upfirdn2d_planes, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, planes, H, W, kernel, kh, kw,
+                     up_x, up_y, down_x, down_y, pad_x0, pad_y0, Ho, Wo, out);
+  MUD_CHECK_LAUNCH("mud_upfirdn2d");
+  return MUD_OK;
+}
+
+template <bool WITH_H, bool WITH_X>
+__global__ __launch_bounds__(256) void k_fir_nhwc(const float* __restrict__ x, int B, int H, int W, int C4, int ldx, FirKernel fk,
+                                                  int kh, int kw, int up, int down, int pad0, int Ho, int Wo,
+                                                  const float* __restrict__ psc, const float* __restrict__ psh, int pro_ld,
+                                                  int pro_mode, float* __restrict__ out_h, int ldh, float* __restrict__ out_x,
+                                                  int ldxo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C4) * 4;
+    int64_t p = idx / C4;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (WITH_H && pro_mode != MUD_PRO_NONE) {
+      sc = *(const f32x4*)(psc + (int64_t)b * pro_ld + c);
+      sh = *(const f32x4*)(psh + (int64_t)b * pro_ld + c);
+    }
+    f32x4 ah = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < kh; ++m) {
+      const int Y = oy * down + m - pad0;
+      if (Y < 0 || Y % up) continue;
+      const int iy = Y / up;
+      if (iy >= H) continue;
+      for (int n = 0; n < kw; ++n) {
+        const int X = ox * down + n - pad0;
+        if (X < 0 || X % up) continue;
+        const int ix = X / up;
+        if (ix >= W) continue;
+        const float kv = fk.k[(kh - 1 - m) * kw + (kw - 1 - n)];
+        const f32x4 v = *(const f32x4*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + c);
+        if (WITH_X) ax += kv * v;
+        if (WITH_H) {
+          f32x4 t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = mud_prologue(v[j], sc[j], sh[j], pro_mode);
+          ah += kv * t;
+        }
+      }
+    }
+    const int64_t op = ((int64_t)b * Ho + oy) * Wo + ox;
+    if (WITH_H) *(f32x4*)(out_h + op * ldh + c) = ah;
+    if (WITH_X) *(f32x4*)(out_x + op * ldxo + c) = ax;
+  }
+}
+
+extern "C" int mud_fir_nhwc(const float* x, int B, int H, int W, int C, int ldx, const float* kernel_host, int kh, int kw, int up,
+                            int down, int pad0, int pad1, const float* pro_scale, const float* pro_shift, int pro_ld,
+                            int pro_mode, float* out_h, int ldh, float* out_x, int ldxo, void* stream) {
+  MUD_REQUIRE(x && kernel_host && (out_h || out_x), "mud_fir_nhwc: null pointer");
+  MUD_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldx >= C && mud_aligned16(x), "mud_fir_nhwc: needs C%%4==0, ld%%4==0, aligned x");
+  MUD_REQUIRE(kh > 0 && kw > 0 && kh * kw <= FIR_MAX_TAPS && up >= 1 && down >= 1, "mud_fir_nhwc: bad filter");
+  MUD_REQUIRE(pro_mode == MUD_PRO_NONE || (pro_scale && pro_shift && pro_ld >= C && out_h), "mud_fir_nhwc: prologue arrays missing");
+  MUD_REQUIRE(!out_h || (ldh >= C && ldh % 4 == 0 && mud_aligned16(out_h)), "mud_fir_nhwc: bad out_h view");
+  MUD_REQUIRE(!out_x || (ldxo >= C && ldxo % 4 == 0 && mud_aligned16(out_x)), "mud_fir_nhwc: bad out_x view");
+  const int Ho = (H * up + pad0 + pad1 - kh) / down + 1, Wo = (W * up + pad0 + pad1 - kw) / down + 1;
+  MUD_REQUIRE(Ho > 0 && Wo > 0, "mud_fir_nhwc: empty output");
+  if (B == 0) return MUD_OK;
+  FirKernel fk;
+  for (int i = 0; i < FIR_MAX_TAPS; ++i) fk.k[i] = i < kh * kw ? kernel_host[i] : 0.f;
+  int64_t blocks = mud_cdiv((int64_t)B * Ho * Wo * (C / 4), 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  dim3 grid((int)blocks), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define FIR_LAUNCH(HH, XX) hipLaunchKernelGGL((k_fir_nhwc<HH, XX>), grid, block, 0, s, x, B, H, W, C / 4, ldx, fk, kh, kw, up, down, pad0, Ho, Wo, pro_scale, pro_shift, pro_ld, pro_mode, out_h, ldh, out_x, ldxo)
+  if (out_h && out_x) FIR_LAUNCH(true, true);
+  else if (out_h) FIR_LAUNCH(true, false);
+  else FIR_LAUNCH(false, true);
+#undef FIR_LAUNCH
+  MUD_CHECK_LAUNCH("mud_fir_nhwc");
+  return MUD_OK;
+}

@@ -1,0 +1,103 @@
+"""ctypes binding of libmudiff_hip.so (include/mudiff_hip.h) for PyTorch-ROCm tensors.
+
+torch is used for device memory and streams only: every function here takes tensors that already
+live on the GPU, checks shapes on the host and enqueues hand-written gfx950 kernels on torch's
+current stream.  There is NO CPU or PyTorch fallback: if the shared library is missing or a tensor is
+not on a GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libmudiff_hip.so')
+_lib = None
+
+ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_SILU = 0, 1, 2, 3
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_SILU = 0, 1, 2
+
+
+class MudiffHipError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    """struct mud_conv_args (include/mudiff_hip.h)."""
+    _fields_ = [
+        ('x', C.c_void_p), ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('ldx', C.c_int),
+        ('w', C.c_void_p), ('w_bstride', C.c_int64),
+        ('ks', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
+        ('pro_scale', C.c_void_p), ('pro_shift', C.c_void_p), ('pro_ld', C.c_int), ('pro_mode', C.c_int),
+        ('bias', C.c_void_p),
+        ('bias2', C.c_void_p), ('bias2_ld', C.c_int),
+        ('res', C.c_void_p), ('ldr', C.c_int),
+        ('out_scale', C.c_float), ('act', C.c_int),
+        ('out', C.c_void_p), ('Cout', C.c_int), ('ldo', C.c_int),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    'mud_version': (C.c_int, []),
+    'mud_last_error': (C.c_char_p, []),
+    'mud_posterior_sample': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _P]),
+    'mud_q_sample': (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _L, _P]),
+    'mud_timestep_embedding': (_I, [_P, _P, _I, _I, _F, _P]),
+    'mud_pixel_norm': (_I, [_P, _P, _I, _I, _P]),
+    'mud_dense': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mud_gn_ws_bytes': (_L, [_I, _L, _I, _I]),
+    'mud_gn_scale_shift': (_I, [_P, _I, _L, _I, _I, _I, _F, _P, _P, _L, _P, _P, _I, _P, _P, _P]),
+    'mud_channel_mean': (_I, [_P, _I, _L, _I, _I, _P, _I, _P, _P]),
+    'mud_conv2d_direct': (_I, [C.POINTER(ConvArgs), _P]),
+    'mud_packed_weight_bytes': (_L, [_I, _I, _I]),
+    'mud_pack_weights': (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
+    'mud_conv2d_mfma': (_I, [C.POINTER(ConvArgs), _P]),
+    'mud_upfirdn2d': (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'mud_fir_nhwc': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
+    'mud_softmax_rows': (_I, [_P, _L, _I, _I, _P]),
+    'mud_mul': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
+    'mud_gate_mix': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libmudiff_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise MudiffHipError(
+                f'{_LIB_PATH} not found: build it with `make -C mu-diff_amd/csrc` (or __graft_entry__.build()). '
+                'There is no CPU / PyTorch fallback for the MU-Diff sampling path.')
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code, what=''):
+    if code != 0:
+        raise MudiffHipError(f'{what or "libmudiff_hip"} failed ({code}): {load().mud_last_error().decode()}')
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MudiffHipError('the MU-Diff HIP path needs tensors on an MI355X (got a CPU tensor); there is no CPU fallback')
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,282 @@
+"""Tensor-level wrappers over the C ABI: NHWC views, shape checks on the host, launches on torch's
+current stream.  Everything here is GPU-only (see mudiff_hip.__init__)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import (ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE, PRO_AFFINE_SILU, PRO_NONE, ConvArgs,  # noqa: F401
+               MudiffHipError, check, load, ptr, require_gpu, stream_ptr)
+
+
+class View:
+    """NHWC fp32 view (ptr, B, H, W, C, ld) into a torch tensor that owns the memory."""
+    __slots__ = ('base', 'B', 'H', 'W', 'C', 'ld', 'c0')
+
+    def __init__(self, base, B, H, W, C, ld=None, c0=0):
+        self.base, self.B, self.H, self.W, self.C = base, B, H, W, C
+        self.ld = C if ld is None else ld
+        self.c0 = c0
+
+    @staticmethod
+    def empty(B, H, W, C, device):
+        return View(torch.empty(B, H, W, C, device=device, dtype=torch.float32), B, H, W, C)
+
+    @staticmethod
+    def from_nchw(x):
+        """NCHW torch tensor -> NHWC view (zero-copy when C == 1)."""
+        require_gpu(x)
+        B, Cc, H, W = x.shape
+        x = x.float()
+        t = x.reshape(B, H, W, 1) if Cc == 1 else x.permute(0, 2, 3, 1)
+        return View(t.contiguous(), B, H, W, Cc)
+
+    def to_nchw(self):
+        t = self.tensor()
+        if self.C == 1:
+            return t.reshape(self.B, 1, self.H, self.W)
+        return t.permute(0, 3, 1, 2).contiguous()
+
+    def tensor(self):
+        """The viewed region as a (possibly non-contiguous) torch tensor [B,H,W,C]."""
+        return self.base.reshape(self.B, self.H, self.W, self.ld)[..., self.c0:self.c0 + self.C]
+
+    def slice(self, c0, C_):
+        assert 0 <= c0 and c0 + C_ <= self.C
+        return View(self.base, self.B, self.H, self.W, C_, self.ld, self.c0 + c0)
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.base.data_ptr() + 4 * self.c0)
+
+    @property
+    def npix(self):
+        return self.B * self.H * self.W
+
+    @property
+    def device(self):
+        return self.base.device
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------
+def posterior_sample(x01, x02, xt, noise, t, coef1, coef2, std_tab, out=None):
+    require_gpu(x01, xt, noise, t, coef1)
+    B = xt.shape[0]
+    per = xt[0].numel() if B else 0
+    x01, xt, noise = _f32(x01.contiguous()), _f32(xt.contiguous()), _f32(noise.contiguous())
+    if x02 is not None:
+        x02 = _f32(x02.contiguous())
+        assert x02.shape == xt.shape
+    assert x01.shape == xt.shape == noise.shape and t.dtype == torch.int64 and t.numel() == B
+    out = torch.empty_like(xt) if out is None else out
+    check(load().mud_posterior_sample(ptr(x01), ptr(x02), ptr(xt), ptr(noise), ptr(t.contiguous()), ptr(coef1), ptr(coef2),
+                                      ptr(std_tab), coef1.numel(), ptr(out), B, per, stream_ptr()), 'mud_posterior_sample')
+    return out
+
+
+def q_sample(x, noise, t, toff, a_tab, s_tab):
+    require_gpu(x, noise, t, a_tab, s_tab)
+    x, noise = _f32(x.contiguous()), _f32(noise.contiguous())
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    check(load().mud_q_sample(ptr(x), ptr(noise), ptr(t.contiguous()), toff, ptr(a_tab), ptr(s_tab), a_tab.numel(), ptr(out), B,
+                              x[0].numel() if B else 0, stream_ptr()), 'mud_q_sample')
+    return out
+
+
+def timestep_embedding(t, dim, max_positions=10000.0):
+    require_gpu(t)
+    assert t.dim() == 1 and t.dtype == torch.int64
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
+    check(load().mud_timestep_embedding(ptr(t.contiguous()), ptr(out), t.shape[0], dim, float(max_positions), stream_ptr()),
+          'mud_timestep_embedding')
+    return out
+
+
+def pixel_norm(z):
+    require_gpu(z)
+    z = _f32(z.contiguous())
+    out = torch.empty_like(z)
+    check(load().mud_pixel_norm(ptr(z), ptr(out), z.shape[0], z.shape[1], stream_ptr()), 'mud_pixel_norm')
+    return out
+
+
+def dense(x, W, bias, act_in=ACT_NONE, act_out=ACT_NONE):
+    """x [B,K] (row stride allowed), W [N,K], bias [N] -> [B,N]."""
+    require_gpu(x, W)
+    assert x.dim() == 2 and x.stride(1) == 1 and W.is_contiguous() and x.shape[1] == W.shape[1]
+    B, K = x.shape
+    N = W.shape[0]
+    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    check(load().mud_dense(ptr(x), x.stride(0) if B > 1 else K, ptr(W), ptr(bias), ptr(out), N, B, K, N, act_in, act_out,
+                           stream_ptr()), 'mud_dense')
+    return out
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _WS[device] = ws
+    return ws
+
+
+def gn_scale_shift(x: View, G, gamma=None, beta=None, eps=1e-6):
+    """-> (scale [B,C], shift [B,C]).  gamma/beta: None, [C] or [B,C] (row-strided views allowed)."""
+    lib = load()
+    HW = x.H * x.W
+    ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, G))
+    ss = torch.empty(2, x.B, x.C, device=x.device, dtype=torch.float32)
+    bstride = 0
+    if gamma is not None:
+        assert gamma.stride(-1) == 1 and beta.stride(-1) == 1 and gamma.shape[-1] == x.C
+        if gamma.dim() == 2:
+            assert gamma.shape[0] == x.B and gamma.stride(0) == beta.stride(0)
+            bstride = gamma.stride(0)
+    check(lib.mud_gn_scale_shift(x.ptr, x.B, HW, x.C, x.ld, G, eps, ptr(gamma), ptr(beta), bstride, ptr(ss[0]), ptr(ss[1]), x.C,
+                                 None, ptr(ws), stream_ptr()), 'mud_gn_scale_shift')
+    return ss[0], ss[1]
+
+
+def channel_mean(x: View):
+    lib = load()
+    HW = x.H * x.W
+    ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, x.C))
+    out = torch.empty(x.B, x.C, device=x.device, dtype=torch.float32)
+    check(lib.mud_channel_mean(x.ptr, x.B, HW, x.C, x.ld, ptr(out), x.C, ptr(ws), stream_ptr()), 'mud_channel_mean')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def pack_weights(src, s_tap, s_ci, s_co, ks, Cin, Cout, nbatch=1, src_bstride=0, src_offset=0):
+    """-> uint8 tensor [nbatch, packed bytes] in the MFMA kernel's B-operand layout."""
+    lib = load()
+    require_gpu(src)
+    nbytes = lib.mud_packed_weight_bytes(ks, Cin, Cout)
+    dst = torch.empty(nbatch, nbytes, device=src.device, dtype=torch.uint8)
+    check(lib.mud_pack_weights(C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch,
+                               ptr(dst), stream_ptr()), 'mud_pack_weights')
+    return dst
+
+
+def pack_conv_weight(w_oihw):
+    """nn.Conv2d weight [O,I,k,k] -> packed MFMA operand."""
+    O, I, k, _ = w_oihw.shape
+    w = _f32(w_oihw.detach().contiguous())
+    return pack_weights(w, 1, k * k, I * k * k, k, I, O)
+
+
+def pack_matrix_in_out(W_in_out):
+    """NIN weight W[in,out] -> packed 1x1 operand."""
+    I, O = W_in_out.shape
+    return pack_weights(_f32(W_in_out.detach().contiguous()), 0, O, 1, 1, I, O)
+
+
+def direct_weight(w_oihw):
+    """[O,I,k,k] -> fp32 [k,k,I,O] for mud_conv2d_direct."""
+    return w_oihw.detach().permute(2, 3, 1, 0).contiguous()
+
+
+def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None, bias2=None, res: View = None,
+         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0):
+    """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode)."""
+    lib = load()
+    pad = ks // 2 if pad is None else pad
+    Ho = (x.H + 2 * pad - ks) // stride + 1
+    Wo = (x.W + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = View.empty(x.B, Ho, Wo, Cout, x.device)
+    assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, Cout), ((out.B, out.H, out.W, out.C), (x.B, Ho, Wo, Cout))
+    a = ConvArgs()
+    a.x, a.B, a.H, a.W, a.Cin, a.ldx = x.ptr, x.B, x.H, x.W, x.C, x.ld
+    a.w, a.w_bstride = ptr(w), w_bstride
+    a.ks, a.stride, a.pad = ks, stride, pad
+    if pro is not None:
+        sc, sh, mode = pro
+        assert sc.shape == (x.B, x.C) and sc.stride(1) == 1 and sh.stride() == sc.stride()
+        a.pro_scale, a.pro_shift, a.pro_ld, a.pro_mode = ptr(sc), ptr(sh), sc.stride(0), mode
+    else:
+        a.pro_mode = PRO_NONE
+    if bias is not None:
+        assert bias.numel() == Cout and bias.is_contiguous()
+        a.bias = ptr(bias)
+    if bias2 is not None:
+        assert bias2.shape == (x.B, Cout) and bias2.stride(1) == 1
+        a.bias2, a.bias2_ld = ptr(bias2), bias2.stride(0)
+    if res is not None:
+        assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, Cout)
+        a.res, a.ldr = res.ptr, res.ld
+    a.out_scale, a.act = out_scale, act
+    a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
+    fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
+    check(fn(C.byref(a), stream_ptr()), 'mud_conv2d_mfma' if mfma else 'mud_conv2d_direct')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def upfirdn2d_planes(x, kernel, up, down, pad):
+    """The reference's native-op boundary: x [N,C,H,W] (any float dtype is computed in fp32)."""
+    require_gpu(x, kernel)
+    N, Cc, H, W = x.shape
+    xin = _f32(x.float().contiguous())
+    k = _f32(kernel.float().contiguous())
+    kh, kw = k.shape
+    (ux, uy), (dx, dy), (px0, px1, py0, py1) = up, down, pad
+    Ho = (H * uy + py0 + py1 - kh) // dy + 1
+    Wo = (W * ux + px0 + px1 - kw) // dx + 1
+    out = torch.empty(N, Cc, Ho, Wo, device=x.device, dtype=torch.float32)
+    check(load().mud_upfirdn2d(ptr(xin), N * Cc, H, W, ptr(k), kh, kw, ux, uy, dx, dy, px0, px1, py0, py1, ptr(out), stream_ptr()),
+          'mud_upfirdn2d')
+    return out.to(x.dtype)
+
+
+def fir_nhwc(x: View, kernel2d, up, down, pad, pro=None, want_h=True, want_x=False):
+    """kernel2d: host list of lists / numpy [kh,kw].  -> (out_h or None, out_x or None)."""
+    import numpy as np
+    k = np.ascontiguousarray(kernel2d, dtype=np.float32)
+    kh, kw = k.shape
+    Ho = (x.H * up + pad[0] + pad[1] - kh) // down + 1
+    Wo = (x.W * up + pad[0] + pad[1] - kw) // down + 1
+    oh = View.empty(x.B, Ho, Wo, x.C, x.device) if want_h else None
+    ox = View.empty(x.B, Ho, Wo, x.C, x.device) if want_x else None
+    sc = sh = None
+    ld = mode = 0
+    if pro is not None:
+        sc, sh, mode = pro
+        ld = sc.stride(0)
+    check(load().mud_fir_nhwc(x.ptr, x.B, x.H, x.W, x.C, x.ld, k.ctypes.data_as(C.POINTER(C.c_float)), kh, kw, up, down, pad[0],
+                              pad[1], ptr(sc), ptr(sh), ld, mode, oh.ptr if oh else None, oh.ld if oh else 0,
+                              ox.ptr if ox else None, ox.ld if ox else 0, stream_ptr()), 'mud_fir_nhwc')
+    return oh, ox
+
+
+def softmax_rows_(s, n):
+    """in-place softmax over the last axis of a contiguous [..., n] tensor."""
+    rows = s.numel() // n
+    check(load().mud_softmax_rows(ptr(s), rows, n, n, stream_ptr()), 'mud_softmax_rows')
+    return s
+
+
+def mul(a: View, b: View, out: View = None):
+    out = View.empty(a.B, a.H, a.W, a.C, a.device) if out is None else out
+    check(load().mud_mul(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.npix, a.C, stream_ptr()), 'mud_mul')
+    return out
+
+
+def gate_mix(g: View, att: View, other: View, out: View):
+    check(load().mud_gate_mix(g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.npix, g.C, stream_ptr()),
+          'mud_gate_mix')
+    return out
+
+
+INV_SQRT2 = 1.0 / math.sqrt(2.0)

@@ -1,0 +1,296 @@
+"""GPU parity: the HIP path (through the C ABI of libmudiff_hip.so) against the CPU oracle and the
+golden vectors recorded from the reference.  Tolerances: bit-exact for the posterior / q_sample
+kernels (un-contracted fp32 in reference order); <= 1e-3 max-abs per diffusion step for the generators
+(BASELINE.json north_star) - the measured error is printed and asserted well below that."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import SMALL_CFGS, demo_conds, load_golden, sampler_inputs, small_conds
+from oracle import mudiff_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = 'cuda:0'
+
+
+def _imports():
+    from mudiff_hip import ops, sampling
+    from backbones import layerspp, up_or_down_sampling
+    from backbones.ncsnpp_generator_adagn_feat import NCSNpp, NCSNpp_adaptive
+    return ops, sampling, layerspp, up_or_down_sampling, NCSNpp, NCSNpp_adaptive
+
+
+def g(t):
+    return t.to(DEV)
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+# ----------------------------------------------------------------------------------------------
+def test_library_loaded_is_in_tree():
+    import mudiff_hip
+    lib = mudiff_hip.load()
+    assert lib.mud_version() >= 100
+    with open('/proc/self/maps') as f:
+        assert 'libmudiff_hip.so' in f.read()
+
+
+def test_posterior_and_q_sample_bit_exact():
+    ops, S, *_ = _imports()
+    gd = load_golden('elementwise.npz')
+    cfg = O.default_config()
+    coef, dcoef = S.Posterior_Coefficients(cfg, DEV), S.Diffusion_Coefficients(cfg, DEV)
+    for f in ('posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped'):
+        assert torch.equal(getattr(coef, f).cpu(), getattr(O.PosteriorCoefficients(cfg), f))
+    x01, x02, xt, t, nz = g(gd['x01']), g(gd['x02']), g(gd['xt']), g(gd['t']), g(gd['noise'])
+    assert torch.equal(S.sample_posterior_combine(coef, x01, x02, xt, t, nz).cpu(), gd['posterior_combine'])
+    assert torch.equal(S.sample_posterior(coef, x01, xt, t, nz).cpu(), gd['posterior'])
+    assert torch.equal(S.q_sample(dcoef, x01, t, noise=nz).cpu(), gd['q_sample'])
+    a, b = S.q_sample_pairs(dcoef, x01, t, noise=g(gd['noise_outer']), noise_inner=g(gd['noise_inner']))
+    assert torch.equal(a.cpu(), gd['q_pair0']) and torch.equal(b.cpu(), gd['q_pair1'])
+    # ragged / empty / unaligned sizes
+    coefo = O.PosteriorCoefficients(cfg)
+    for B, shape in ((3, (1, 7, 9)), (1, (1, 1, 1)), (0, (1, 8, 8)), (2, (1, 256, 256))):
+        gen = torch.Generator().manual_seed(B + shape[1])
+        xs = [torch.randn(B, *shape, generator=gen) for _ in range(4)]
+        tt = torch.randint(0, 4, (B,), generator=gen)
+        ref = O.sample_posterior_combine(coefo, xs[0], xs[1], xs[2], tt, xs[3])
+        out = S.sample_posterior_combine(coef, g(xs[0]), g(xs[1]), g(xs[2]), g(tt), g(xs[3]))
+        assert torch.equal(out.cpu(), ref)
+
+
+def test_embeddings_and_dense():
+    ops, *_ = _imports()
+    t = torch.tensor([0, 1, 2, 3, 7, 999])
+    assert maxdiff(ops.timestep_embedding(g(t), 64), O.timestep_embedding(t, 64)) < 2e-4   # |arg| up to 999
+    assert maxdiff(ops.timestep_embedding(g(t[:4]), 64), O.timestep_embedding(t[:4], 64)) < 1e-6
+    gen = torch.Generator().manual_seed(0)
+    z = torch.randn(5, 100, generator=gen)
+    ref = z / torch.sqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+    assert maxdiff(ops.pixel_norm(g(z)), ref) < 1e-6
+    for B, K, N in ((5, 100, 256), (1, 256, 1024), (9, 64, 33), (32, 256, 512)):
+        x, W, b = torch.randn(B, K, generator=gen), torch.randn(N, K, generator=gen) / math.sqrt(K), torch.randn(N, generator=gen)
+        assert maxdiff(ops.dense(g(x), g(W), g(b)), F.linear(x, W, b)) < 5e-6
+        assert maxdiff(ops.dense(g(x), g(W), g(b), act_in=ops.ACT_SILU, act_out=ops.ACT_SILU), F.silu(F.linear(F.silu(x), W, b))) < 5e-6
+
+
+@pytest.mark.parametrize('B,H,W,C,G', [(2, 8, 8, 16, 4), (1, 64, 64, 256, 32), (3, 17, 5, 24, 6), (2, 32, 32, 192, 32),
+                                       (1, 256, 256, 64, 16), (2, 16, 16, 320, 32)])
+def test_groupnorm_scale_shift(B, H, W, C, G):
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(C)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.7 + 0.6
+    gamma, beta = torch.randn(B, C, generator=gen), torch.randn(B, C, generator=gen)
+    xv = ops.View.from_nchw(g(x))
+    sc, sh = ops.gn_scale_shift(xv, G, g(gamma), g(beta))
+    got = x * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    ref = gamma[:, :, None, None] * F.group_norm(x, G, eps=1e-6) + beta[:, :, None, None]
+    assert maxdiff(got, ref) < 2e-5
+    # view with a channel offset inside a wider buffer
+    wide = torch.zeros(B, H, W, C + 8, device=DEV)
+    wide[..., 4:4 + C] = g(x).permute(0, 2, 3, 1)
+    v = ops.View(wide, B, H, W, C + 8).slice(4, C)
+    sc2, sh2 = ops.gn_scale_shift(v, G)
+    ref2 = F.group_norm(x, G, eps=1e-6)
+    assert maxdiff(x * sc2.cpu()[:, :, None, None] + sh2.cpu()[:, :, None, None], ref2) < 2e-5
+    assert maxdiff(ops.channel_mean(v), x.mean(dim=(2, 3))) < 1e-6
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,ks,stride,pad', [(2, 12, 20, 1, 64, 3, 1, 1), (1, 9, 7, 64, 1, 3, 1, 1), (2, 13, 13, 8, 16, 3, 2, 0),
+                                                           (1, 8, 8, 3, 5, 3, 1, 1), (2, 6, 6, 16, 8, 1, 1, 0)])
+def test_conv_direct(B, H, W, Cin, Cout, ks, stride, pad):
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, ks, ks, generator=gen) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=gen)
+    out = ops.conv(ops.View.from_nchw(g(x)), ops.direct_weight(g(w)), ks, Cout, mfma=False, stride=stride, pad=pad, bias=g(b))
+    assert maxdiff(out.to_nchw(), F.conv2d(x, w, b, stride=stride, padding=pad)) < 1e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,ks', [(2, 8, 32, 32, 64, 3), (1, 20, 37, 48, 96, 3), (2, 16, 16, 80, 16, 3), (1, 64, 64, 256, 256, 3),
+                                              (1, 33, 9, 8, 24, 3), (2, 16, 16, 64, 128, 1), (1, 5, 7, 36, 40, 1), (1, 64, 64, 256, 768, 1)])
+def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(Cin + 3 * Cout + ks)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, ks, ks, generator=gen) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=gen)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
+    out = ops.conv(ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ks, Cout, mfma=True, bias=g(b)).to_nchw()
+    err = maxdiff(out, ref)
+    fp32_err = maxdiff(F.conv2d(x, w, b, padding=ks // 2), ref)
+    print(f'conv_mfma {B}x{H}x{W} {Cin}->{Cout} k{ks}: split-bf16 err {err:.2e}, torch fp32 err {fp32_err:.2e}')
+    assert err < 3e-5
+    # fused prologue (AdaGN affine + SiLU), time-embedding bias, residual, rescale, activation
+    sc, sh = torch.randn(B, Cin, generator=gen), torch.randn(B, Cin, generator=gen)
+    b2, res = torch.randn(B, Cout, generator=gen), torch.randn(B, Cout, H, W, generator=gen)
+    xin = F.silu(x * sc[:, :, None, None] + sh[:, :, None, None])
+    ref = torch.tanh((F.conv2d(xin, w, b, padding=ks // 2) + b2[:, :, None, None] + res) * 0.5)
+    out = ops.conv(ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ks, Cout, mfma=True, bias=g(b), bias2=g(b2),
+                   pro=(g(sc), g(sh), ops.PRO_AFFINE_SILU), res=ops.View.from_nchw(g(res)), out_scale=0.5, act=ops.ACT_TANH).to_nchw()
+    assert maxdiff(out, ref) < 3e-5
+
+
+def test_fir_against_reference_golden():
+    ops, S, L, UD, *_ = _imports()
+    from utils.op import upfirdn2d
+    gd = load_golden('fir.npz')
+    for tag in 'abc':
+        x = g(gd[f'{tag}.x'])
+        assert maxdiff(UD.upsample_2d(x, (1, 3, 3, 1), factor=2), gd[f'{tag}.up']) < 1e-6
+        assert maxdiff(UD.downsample_2d(x, (1, 3, 3, 1), factor=2), gd[f'{tag}.down']) < 1e-6
+        assert maxdiff(UD.conv_downsample_2d(x, g(gd[f'{tag}.w']), k=(1, 3, 3, 1)), gd[f'{tag}.convdown']) < 3e-6
+    for tag, (u, d, pad) in (('g1', (1, 1, (2, 1))), ('g2', (2, 1, (2, 1))), ('g3', (1, 2, (1, 1))), ('g4', (2, 2, (3, 0)))):
+        assert maxdiff(upfirdn2d(g(gd['g.x']), g(gd['g.k']), up=u, down=d, pad=pad), gd[f'{tag}.out']) < 3e-6
+    # NHWC form with the AdaGN+SiLU prologue and the dual output
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 12, 10, 14, generator=gen)
+    sc, sh = torch.randn(2, 12, generator=gen), torch.randn(2, 12, generator=gen)
+    for mode, fn in (('up', O.upsample_2d), ('down', O.downsample_2d)):
+        kk, up, down, pad = UD.fir_params(mode, (1, 3, 3, 1))
+        oh, ox = ops.fir_nhwc(ops.View.from_nchw(g(x)), kk, up, down, pad, pro=(g(sc), g(sh), ops.PRO_AFFINE_SILU), want_h=True, want_x=True)
+        assert maxdiff(ox.to_nchw(), fn(x)) < 1e-6
+        assert maxdiff(oh.to_nchw(), fn(F.silu(x * sc[:, :, None, None] + sh[:, :, None, None]))) < 2e-6
+
+
+def test_softmax_and_gates():
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(9)
+    for rows, n in ((7, 64), (33, 4096), (5, 1000)):
+        s = torch.randn(rows, n, generator=gen) * 3
+        assert maxdiff(ops.softmax_rows_(g(s).clone(), n), F.softmax(s, dim=-1)) < 1e-6
+    a, b, c = (torch.randn(2, 16, 6, 5, generator=gen) for _ in range(3))
+    va, vb, vc = (ops.View.from_nchw(g(t)) for t in (a, b, c))
+    assert maxdiff(ops.mul(va, vb).to_nchw(), a * b) < 1e-7
+    out = ops.View.empty(2, 6, 5, 16, DEV)
+    assert maxdiff(ops.gate_mix(va, vb, vc, out).to_nchw(), a * b + (1 - a) * c) < 1e-6
+
+
+def test_blocks_against_reference_golden():
+    ops, S, L, UD, *_ = _imports()
+    import torch.nn as nn
+    gd = load_golden('blocks.npz')
+    act = nn.SiLU()
+
+    def load(mod, prefix):
+        sd = {k[len(prefix) + 1:]: v for k, v in gd.items() if k.startswith(prefix + '.')}
+        mod.load_state_dict(sd, strict=True)
+        return mod.to(DEV)
+    zemb, temb = g(gd['zemb']), g(gd['temb'])
+    zd, td = zemb.shape[1], temb.shape[1]
+    for tag, cin, cout, up, down in (('plain', 8, 8, 0, 0), ('skip', 8, 16, 0, 0), ('up', 12, 12, 1, 0), ('down', 8, 8, 0, 1), ('cat', 24, 16, 0, 0)):
+        m = load(L.ResnetBlockBigGANpp_Adagn(act, cin, cout, temb_dim=td, zemb_dim=zd, up=bool(up), down=bool(down), dropout=0.0, fir=True,
+                                             fir_kernel=(1, 3, 3, 1), skip_rescale=True, init_scale=0.), f'res_{tag}.sd')
+        err = maxdiff(m(g(gd[f'res_{tag}.x']), temb, zemb), gd[f'res_{tag}.y'])
+        print(f'resblock.{tag}: {err:.2e}')
+        assert err < 5e-5, tag
+    m = load(L.AdaptiveGroupNorm(4, 16, zd), 'adagn.sd')
+    assert maxdiff(m(g(gd['adagn.x']), zemb), gd['adagn.y']) < 1e-5
+    for tag, c in (('c16', 16), ('c32', 32)):
+        m = load(L.AttnBlockpp(c, skip_rescale=True, init_scale=0.), f'attn_{tag}.sd')
+        err = maxdiff(m(g(gd[f'attn_{tag}.x'])), gd[f'attn_{tag}.y'])
+        print(f'attn.{tag}: {err:.2e}')
+        assert err < 5e-5
+    x1 = g(gd['feat.x'])
+    assert maxdiff(load(L.ConvFeatBlock(act, in_ch=1, out_ch=16), 'feat.sd')(x1), gd['feat.y']) < 5e-5
+    assert maxdiff(load(L.ConvBlock(act, in_ch=1, out_ch=16, zemb_dim=zd), 'ada.sd')(x1, zemb), gd['ada.y']) < 5e-5
+    assert maxdiff(load(L.ConvBlock_GAP(act, in_ch=1, out_ch=16, zemb_dim=zd), 'gap.sd')(x1), gd['gap.y']) < 5e-5
+    for tag, cin, cout in (('p1', 1, 8), ('p8', 8, 16)):
+        m = load(L.Downsample(in_ch=cin, out_ch=cout, with_conv=True, fir=True, fir_kernel=(1, 3, 3, 1)), f'pyr_{tag}.sd')
+        assert maxdiff(m(g(gd[f'pyr_{tag}.x'])), gd[f'pyr_{tag}.y']) < 1e-5
+
+
+def _build(cfg, seed=1234):
+    *_, NCSNpp, NCSNpp_adaptive = _imports()
+    g1, g2 = NCSNpp(cfg), NCSNpp_adaptive(cfg)
+    g1.load_state_dict(O.make_state_dict(cfg, 'g1', seed))
+    g2.load_state_dict(O.make_state_dict(cfg, 'g2', seed))
+    return g1.to(DEV).eval(), g2.to(DEV).eval()
+
+
+@pytest.mark.parametrize('tag', list(SMALL_CFGS))
+def test_small_models_every_step_vs_reference(tag):
+    ops, S, *_ = _imports()
+    gd = load_golden('small_models.npz')
+    cfg = O.default_config(**SMALL_CFGS[tag])
+    g1, g2 = _build(cfg)
+    conds = [g(c) for c in small_conds(cfg)]
+    x_init, zs, noises = sampler_inputs(cfg, 2)
+    coef = S.Posterior_Coefficients(cfg, DEV)
+    x, steps = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], cfg.num_timesteps, g(x_init), None, cfg,
+                                   zs=[g(z) for z in zs], noises=[g(n) for n in noises], return_steps=True)
+    worst = 0.0
+    for k, st in enumerate(steps):
+        for nm, v in zip(('x01', 'x02', 'xnew'), st):
+            worst = max(worst, maxdiff(v, gd[f'{tag}.step{k}.{nm}']))
+    print(f'{tag}: worst per-step max-abs vs reference = {worst:.2e}')
+    assert worst <= 1e-3
+
+
+def test_config2_full_size_every_step_vs_reference():
+    """BASELINE config 2: 256x256, nf=64, ch_mult 1-2-4, 4 steps, dual generator, injected noise."""
+    ops, S, *_ = _imports()
+    gd = load_golden('full_cfg2.npz')
+    cfg = O.default_config()
+    g1, g2 = _build(cfg)
+    conds = [g(c) for c in demo_conds()]
+    x_init, zs, noises = sampler_inputs(cfg, 1)
+    coef = S.Posterior_Coefficients(cfg, DEV)
+    x, steps = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], 4, g(x_init), None, cfg,
+                                   zs=[g(z) for z in zs], noises=[g(n) for n in noises], return_steps=True)
+    for k, st in enumerate(steps):
+        errs = [maxdiff(v, gd[f'step{k}.{nm}']) for nm, v in zip(('x01', 'x02', 'xnew'), st)]
+        print(f'cfg2 step {k}: max-abs x01 {errs[0]:.2e} x02 {errs[1]:.2e} xnew {errs[2]:.2e}')
+        assert max(errs) <= 1e-3
+    # PSNR / SSIM of the final sample against the demo target, build vs reference: within +-0.05 dB / +-0.001
+    from helpers import preprocess_demo
+    tgt = preprocess_demo(load_golden('demo_inputs_u8.npz')['t1ce'].numpy())[0, 0].numpy()
+    to01 = lambda a: (np.asarray(a, np.float64) + 1) / 2
+    ours, ref = x.cpu()[0, 0].numpy(), gd['step3.xnew'][0, 0].numpy()
+    dp = O.psnr(to01(tgt), to01(ours)) - O.psnr(to01(tgt), to01(ref))
+    ds = O.ssim(to01(tgt), to01(ours)) - O.ssim(to01(tgt), to01(ref))
+    print(f'cfg2: dPSNR {dp:+.4f} dB, dSSIM {ds:+.5f}')
+    assert abs(dp) <= 0.05 and abs(ds) <= 0.001
+
+
+def test_graph_sampler_matches_eager_and_batches():
+    ops, S, *_ = _imports()
+    cfg = O.default_config(**SMALL_CFGS['s32'])
+    g1, g2 = _build(cfg)
+    B = 3
+    gen = torch.Generator().manual_seed(77)
+    conds = [g(torch.tanh(torch.randn(B, 1, 32, 32, generator=gen))) for _ in range(3)]
+    x_init = g(torch.randn(B, 1, 32, 32, generator=gen))
+    zs = [g(torch.randn(B, cfg.nz, generator=gen)) for _ in range(4)]
+    noises = [g(torch.randn(B, 1, 32, 32, generator=gen)) for _ in range(4)]
+    coef = S.Posterior_Coefficients(cfg, DEV)
+    eager = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], 4, x_init, None, cfg, zs=zs, noises=noises)
+    gs = S.GraphSampler(coef, g1, g2, cfg, B, 32, 32, DEV)
+    graphed = gs.sample(conds[0], conds[1], conds[2], x_init, 4, zs=zs, noises=noises)
+    assert torch.equal(eager, graphed)
+    # slices are independent: sample 1 alone == sample 1 inside the batch (data-parallel sharding is exact)
+    solo = S.sample_from_model(coef, g1, conds[0][1:2], g2, conds[1][1:2], conds[2][1:2], 4, x_init[1:2], None, cfg,
+                               zs=[z[1:2] for z in zs], noises=[n[1:2] for n in noises])
+    assert maxdiff(solo, eager[1:2]) < 1e-5
+    # oracle on the same batch
+    sd1, sd2 = O.make_state_dict(cfg, 'g1', 1234), O.make_state_dict(cfg, 'g2', 1234)
+    ref = O.sample_from_model(O.PosteriorCoefficients(cfg), sd1, sd2, cfg, *[c.cpu() for c in conds], x_init.cpu(),
+                              [z.cpu() for z in zs], [n.cpu() for n in noises])
+    assert maxdiff(eager, ref) <= 1e-3
+
+
+def test_cpu_tensors_fail_loudly():
+    *_, NCSNpp, _ = _imports()
+    import mudiff_hip
+    cfg = O.default_config(**SMALL_CFGS['s32na'])
+    m = NCSNpp(cfg)
+    z = torch.zeros(1, 1, 32, 32)
+    with pytest.raises(mudiff_hip.MudiffHipError):
+        m(z, z, z, z, torch.zeros(1, dtype=torch.int64), torch.zeros(1, cfg.nz))
