@@ -37,6 +37,19 @@ def fir_params(mode, k=None, factor=2, gain=1, conv_k=3):
     raise ValueError(mode)
 
 
+_DEV_KERNELS = {}
+
+
+def _device_kernel(kk, device):
+    """FIR taps as a cached device tensor (no host->device copy per call, so hipGraph capture works)."""
+    key = (kk.tobytes(), kk.shape, str(device))
+    t = _DEV_KERNELS.get(key)
+    if t is None:
+        t = torch.tensor(kk, device=device, dtype=torch.float32)
+        _DEV_KERNELS[key] = t
+    return t
+
+
 def upsample_2d(x, k=None, factor=2, gain=1):
     kk, up, down, pad = fir_params('up', k, factor, gain)
     return upfirdn2d(x, torch.tensor(kk, device=x.device, dtype=x.dtype), up=up, pad=pad)
@@ -97,7 +110,7 @@ class Conv2d(nn.Module):
             xf, _ = ops.fir_nhwc(x, kk, up, down, pad)
         else:   # single-channel image pyramid: NHWC == planes
             assert x.C == 1 and x.ld == 1
-            t = upfirdn2d(x.base.reshape(x.B, 1, x.H, x.W), torch.tensor(kk, device=x.device), pad=pad)
+            t = upfirdn2d(x.base.reshape(x.B, 1, x.H, x.W), _device_kernel(kk, x.device), pad=pad)
             xf = View(t, x.B, t.shape[2], t.shape[3], 1)
         return ops.conv(xf, self._weights(), self.kernel, self.weight.shape[0], mfma=False, stride=2, pad=0, bias=bias, res=res,
                         out_scale=out_scale, out=out)

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ x01
                                                    const int64_t* __restrict__ t, const float* __restrict__ c1t,
                                                    const float* __restrict__ c2t, const float* __restrict__ sdt,
                                                    int ntab, float* __restrict__ out, int64_t per_sample) {
+#pragma clang fp contract(off)   // every * and + below rounds separately, like the reference's chain of torch ops
   const int b = blockIdx.y;
   int64_t ti = t[b];
   ti = ti < 0 ? 0 : (ti >= ntab ? ntab - 1 : ti);
@@ -42,13 +43,13 @@ __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ x01
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float cx = __fmul_rn(c2, x[j]);
-      float mean = __fadd_rn(__fmul_rn(c1, a[j]), cx);
+      const float cx = c2 * x[j];
+      float mean = c1 * a[j] + cx;
       if (DUAL) {
-        const float m2 = __fadd_rn(__fmul_rn(c1, bb[j]), cx);
-        mean = __fmul_rn(__fadd_rn(mean, m2), 0.5f);   // (mean1 + mean2) / 2, exact halving
+        const float m2 = c1 * bb[j] + cx;
+        mean = (mean + m2) * 0.5f;   // (mean1 + mean2) / 2, exact halving
       }
-      o[j] = __fadd_rn(mean, __fmul_rn(sd, n[j]));
+      o[j] = mean + sd * n[j];
     }
     if (VEC) *(f32x4*)(out + base + i) = *(f32x4*)o;
     else out[base + i] = o[0];
@@ -58,10 +59,10 @@ __global__ __launch_bounds__(256) void k_posterior(const float* __restrict__ x01
 extern "C" int mud_posterior_sample(const float* x01, const float* x02, const float* xt, const float* noise,
                                     const int64_t* t, const float* coef1, const float* coef2, const float* std_tab,
                                     int ntab, float* out, int B, int64_t per_sample, void* stream) {
-  MUD_REQUIRE(x01 && xt && noise && t && coef1 && coef2 && std_tab && out, "mud_posterior_sample: null pointer");
   MUD_REQUIRE(B >= 0 && per_sample >= 0 && ntab > 0, "mud_posterior_sample: bad sizes B=%d per_sample=%lld ntab=%d", B,
               (long long)per_sample, ntab);
-  if (B == 0 || per_sample == 0) return MUD_OK;
+  if (B == 0 || per_sample == 0) return MUD_OK;   // empty batch: nothing to do (pointers may be null)
+  MUD_REQUIRE(x01 && xt && noise && t && coef1 && coef2 && std_tab && out, "mud_posterior_sample: null pointer");
   MUD_REQUIRE(B <= 65535, "mud_posterior_sample: B=%d exceeds 65535", B);
   const bool vec = (per_sample % 4 == 0) && mud_aligned16(x01) && mud_aligned16(xt) && mud_aligned16(noise) &&
                    mud_aligned16(out) && (!x02 || mud_aligned16(x02));
@@ -79,20 +80,21 @@ __global__ __launch_bounds__(256) void k_q_sample(const float* __restrict__ x, c
                                                   const int64_t* __restrict__ t, int toff, const float* __restrict__ at,
                                                   const float* __restrict__ st, int ntab, float* __restrict__ out,
                                                   int64_t per_sample) {
+#pragma clang fp contract(off)
   const int b = blockIdx.y;
   int64_t ti = t[b] + toff;
   ti = ti < 0 ? 0 : (ti >= ntab ? ntab - 1 : ti);
   const float a = at[ti], sg = st[ti];
   const int64_t base = (int64_t)b * per_sample;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * blockDim.x)
-    out[base + i] = __fadd_rn(__fmul_rn(a, x[base + i]), __fmul_rn(sg, noise[base + i]));
+    out[base + i] = a * x[base + i] + sg * noise[base + i];
 }
 
 extern "C" int mud_q_sample(const float* x, const float* noise, const int64_t* t, int toff, const float* a_tab,
                             const float* s_tab, int ntab, float* out, int B, int64_t per_sample, void* stream) {
-  MUD_REQUIRE(x && noise && t && a_tab && s_tab && out, "mud_q_sample: null pointer");
   MUD_REQUIRE(B >= 0 && per_sample >= 0 && ntab > 0 && B <= 65535, "mud_q_sample: bad sizes");
   if (B == 0 || per_sample == 0) return MUD_OK;
+  MUD_REQUIRE(x && noise && t && a_tab && s_tab && out, "mud_q_sample: null pointer");
   dim3 grid(mud_grid_1d(per_sample, 256), B), block(256);
   hipLaunchKernelGGL(k_q_sample, grid, block, 0, (hipStream_t)stream, x, noise, t, toff, a_tab, s_tab, ntab, out, per_sample);
   MUD_CHECK_LAUNCH("mud_q_sample");

@@ -42,25 +42,37 @@ def test_library_loaded_is_in_tree():
 
 
 def test_posterior_and_q_sample_bit_exact():
+    """The kernels reproduce the reference's chain of separately-rounded fp32 mul/add exactly: compared
+    bit-for-bit with the oracle evaluated on THIS host from the same tables.  (Host-side tables use
+    float64 exp/log whose last bit depends on the CPU's SIMD dispatch, so against the golden recorded in
+    the build container the comparison allows 1 ulp.)"""
     ops, S, *_ = _imports()
     gd = load_golden('elementwise.npz')
     cfg = O.default_config()
     coef, dcoef = S.Posterior_Coefficients(cfg, DEV), S.Diffusion_Coefficients(cfg, DEV)
+    ocoef, odcoef = O.PosteriorCoefficients(cfg), O.DiffusionCoefficients(cfg)
+    kat = load_golden('kat_schedules.npz')
     for f in ('posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped'):
-        assert torch.equal(getattr(coef, f).cpu(), getattr(O.PosteriorCoefficients(cfg), f))
-    x01, x02, xt, t, nz = g(gd['x01']), g(gd['x02']), g(gd['xt']), g(gd['t']), g(gd['noise'])
-    assert torch.equal(S.sample_posterior_combine(coef, x01, x02, xt, t, nz).cpu(), gd['posterior_combine'])
-    assert torch.equal(S.sample_posterior(coef, x01, xt, t, nz).cpu(), gd['posterior'])
-    assert torch.equal(S.q_sample(dcoef, x01, t, noise=nz).cpu(), gd['q_sample'])
-    a, b = S.q_sample_pairs(dcoef, x01, t, noise=g(gd['noise_outer']), noise_inner=g(gd['noise_inner']))
-    assert torch.equal(a.cpu(), gd['q_pair0']) and torch.equal(b.cpu(), gd['q_pair1'])
+        assert torch.equal(getattr(coef, f).cpu(), getattr(ocoef, f))
+        torch.testing.assert_close(getattr(coef, f).cpu(), kat[f'T4.{f}'], rtol=3e-7, atol=0)
+    x01, x02, xt, t, nz = gd['x01'], gd['x02'], gd['xt'], gd['t'], gd['noise']
+    out = S.sample_posterior_combine(coef, g(x01), g(x02), g(xt), g(t), g(nz)).cpu()
+    assert torch.equal(out, O.sample_posterior_combine(ocoef, x01, x02, xt, t, nz))
+    assert maxdiff(out, gd['posterior_combine']) <= 2.4e-7
+    out = S.sample_posterior(coef, g(x01), g(xt), g(t), g(nz)).cpu()
+    assert torch.equal(out, O.sample_posterior(ocoef, x01, xt, t, nz)) and maxdiff(out, gd['posterior']) <= 2.4e-7
+    out = S.q_sample(dcoef, g(x01), g(t), noise=g(nz)).cpu()
+    assert torch.equal(out, O.q_sample(odcoef, x01, t, nz)) and maxdiff(out, gd['q_sample']) <= 2.4e-7
+    a, b = S.q_sample_pairs(dcoef, g(x01), g(t), noise=g(gd['noise_outer']), noise_inner=g(gd['noise_inner']))
+    oa, ob = O.q_sample_pairs(odcoef, x01, t, gd['noise_inner'], gd['noise_outer'])
+    assert torch.equal(a.cpu(), oa) and torch.equal(b.cpu(), ob)
+    assert maxdiff(a, gd['q_pair0']) <= 2.4e-7 and maxdiff(b, gd['q_pair1']) <= 4.8e-7
     # ragged / empty / unaligned sizes
-    coefo = O.PosteriorCoefficients(cfg)
     for B, shape in ((3, (1, 7, 9)), (1, (1, 1, 1)), (0, (1, 8, 8)), (2, (1, 256, 256))):
         gen = torch.Generator().manual_seed(B + shape[1])
         xs = [torch.randn(B, *shape, generator=gen) for _ in range(4)]
         tt = torch.randint(0, 4, (B,), generator=gen)
-        ref = O.sample_posterior_combine(coefo, xs[0], xs[1], xs[2], tt, xs[3])
+        ref = O.sample_posterior_combine(ocoef, xs[0], xs[1], xs[2], tt, xs[3])
         out = S.sample_posterior_combine(coef, g(xs[0]), g(xs[1]), g(xs[2]), g(tt), g(xs[3]))
         assert torch.equal(out.cpu(), ref)
 
