@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py - MU-Diff reverse-diffusion sampling throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic slices: the complete 4-step
+dual-generator reverse sampling (4 x [G1 -> G2 -> posterior]) of B 256x256 slices per GPU (BASELINE
+config 2 shapes: nf=64, ch_mult 1-2-4, 2 res blocks, nz=100; weights from the seed scheme - no trained
+weights exist offline; noise drawn on the device).  value = slices/s over ALL ranks = N*B*K / max-over-
+ranks wall time, inputs resident in HBM, fp32 in / fp32 out.
+
+One JSON line on rank 0, with
+  roofline      the dominant kernel (3x3 implicit-GEMM conv on split-bf16 MFMA): algorithmic FLOPs /
+                per-launch HIP-event time, measured in an instrumented pass of the same workload;
+  cpu_baseline  the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's cores on
+                a bounded sample (1 slice), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, 'mu-diff_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+FLOP_PER_SLICE = 3456.4e9        # 4 x (378.87 + 485.24) GFLOP, B=1
+FUSED_BYTES_PER_SLICE = 19.9e9   # algorithmic HBM bytes, fully fused ideal
+PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '8')), help='slices per GPU per step')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def build_models(cfg, dev, rank, world):
+    from oracle import mudiff_oracle as O      # weights-from-seed scheme only (no oracle arithmetic here)
+    from backbones.ncsnpp_generator_adagn_feat import NCSNpp, NCSNpp_adaptive
+    g1, g2 = NCSNpp(cfg), NCSNpp_adaptive(cfg)
+    if rank == 0:
+        g1.load_state_dict(O.make_state_dict(cfg, 'g1', 1234))
+        g2.load_state_dict(O.make_state_dict(cfg, 'g2', 1234))
+    g1, g2 = g1.to(dev).eval(), g2.to(dev).eval()
+    if world > 1:
+        # parameters live on rank 0 (checkpoint reader); one flattened RCCL broadcast per generator over xGMI
+        import torch.distributed as dist
+        for m in (g1, g2):
+            params = [p.data for p in m.parameters()]
+            flat = torch.cat([p.reshape(-1) for p in params])
+            dist.broadcast(flat, src=0)
+            off = 0
+            for p in params:
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+    return g1, g2
+
+
+def synthetic_batch(cfg, B, dev, seed):
+    """BraTS-shaped synthetic slices: smooth z-scored fields clamped to [-1,1] inside a disc, zero (-1)
+    background (dataset/dataset_brats.py:83,91 contract)."""
+    g = torch.Generator().manual_seed(seed)
+    H = cfg.image_size
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, H), indexing='ij')
+    mask = ((yy ** 2 + xx ** 2) < 0.8).float()
+    out = []
+    for _ in range(3):
+        f = torch.randn(B, 1, H // 8, H // 8, generator=g)
+        f = torch.nn.functional.interpolate(f, size=(H, H), mode='bilinear', align_corners=False)
+        out.append((torch.clamp(f * 1.5, -3, 3) / 3 * mask + (mask - 1)).to(dev))
+    return out
+
+
+def cpu_baseline(cfg):
+    from oracle import mudiff_oracle as O
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, int(os.environ.get('MUDIFF_CPU_THREADS', '16'))))   # the 1-GPU box's CPU share is 16
+    torch.set_num_threads(ncores)
+    sd1, sd2 = O.make_state_dict(cfg, 'g1', 1234), O.make_state_dict(cfg, 'g2', 1234)
+    g = torch.Generator().manual_seed(5)
+    H = cfg.image_size
+    conds = [torch.tanh(torch.randn(1, 1, H, H, generator=g)) for _ in range(3)]
+    x0 = torch.randn(1, 1, H, H, generator=g)
+    zs = [torch.randn(1, cfg.nz, generator=g) for _ in range(cfg.num_timesteps)]
+    ns = [torch.randn(1, 1, H, H, generator=g) for _ in range(cfg.num_timesteps)]
+    coef = O.PosteriorCoefficients(cfg)
+    with torch.no_grad():
+        O.g1_forward(sd1, cfg, x0, *conds, torch.zeros(1, dtype=torch.int64), zs[0])      # warm-up (thread pool, oneDNN primitives)
+        t0 = time.perf_counter()
+        O.sample_from_model(coef, sd1, sd2, cfg, *conds, x0, zs, ns)
+        dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 5), unit='slices/s', cores=ncores, kind='port',
+                sample=f'1 slice (B=1, {cfg.num_timesteps} steps, both generators, 256x256, nf=64) after a 1-forward warm-up; '
+                       f'{dt:.2f} s; torch {torch.__version__} CPU fp32')
+
+
+def log(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU fallback for the HIP path'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)   # nccl == RCCL on ROCm
+
+    from oracle import mudiff_oracle as O
+    from mudiff_hip import ops, sampling as S
+    cfg = O.default_config()
+    B, K, W = a.batch, a.steps, a.warmup
+    H = cfg.image_size
+    g1, g2 = build_models(cfg, dev, rank, world)
+    coef = S.Posterior_Coefficients(cfg, dev)
+    c1, c2, c3 = synthetic_batch(cfg, B, dev, seed=100 + rank)     # each rank owns its shard of slices
+    x_init = torch.randn(B, 1, H, H, device=dev)
+
+    log(f'models built, rank {rank}/{world}, B={B}')
+    if a.no_graph:
+        def one_step():
+            return S.sample_from_model(coef, g1, c1, g2, c2, c3, cfg.num_timesteps, x_init, None, cfg)
+    else:
+        sampler = S.GraphSampler(coef, g1, g2, cfg, B, H, H, dev)
+
+        def one_step():
+            return sampler.sample(c1, c2, c3, x_init, cfg.num_timesteps)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log('sampler ready (hipGraph captured)' if not a.no_graph else 'eager mode')
+    for _ in range(W):
+        out = one_step()
+    barrier()
+    log('warm-up done')
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    slices = world * B * K
+    value = slices / dt
+    log(f'timed region: {dt:.3f} s for {slices} slices -> {value:.2f} slices/s')
+    line = {
+        'metric': '256x256 slices/sec (4-step dual-gen reverse)', 'value': round(value, 3), 'unit': 'slices/s',
+        'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * dt / K, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (convs/attention: bf16 hi+lo split MFMA x3, fp32 accumulate)',
+        'data': 'synthetic',
+        'config': {'workload': f'BASELINE config 2 shapes: 4-step dual-generator sampling, 256x256, nf=64, ch_mult 1-2-4, '
+                               f'{B} slices per GPU per step, batch-sharded over {world} GPU(s), weights replicated',
+                   'slices_per_gpu_per_step': B, 'hipgraph': not a.no_graph},
+        'end_to_end': {'fp32_flop_frac': round(value * FLOP_PER_SLICE / 1e12 / world / PEAK_FP32_TFLOPS, 4),
+                       'bf16x3_issued_frac': round(3 * value * FLOP_PER_SLICE / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+                       'fused_hbm_frac': round(value * FUSED_BYTES_PER_SLICE / 1e9 / world / PEAK_HBM_GBS, 4)},
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # instrumented eager pass of the same workload: HIP events around every launch of the dominant kernel
+        ops.PROFILE.enable()
+        S.sample_from_model(coef, g1, c1, g2, c2, c3, cfg.num_timesteps, x_init, None, cfg)
+        torch.cuda.synchronize()
+        prof = ops.PROFILE.summary()
+        ops.PROFILE.disable()
+        k = prof.get('conv_mfma_k3')
+        if k:
+            ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
+            line['roofline'] = {'kernel': 'k_conv_mfma<3> (3x3 implicit GEMM, split-bf16 MFMA)', 'bound': 'mfma',
+                                'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+                                'traffic': None,
+                                'launches': k['n'], 'avg_launch_us': round(1e3 * k['ms'] / k['n'], 2),
+                                'algorithmic_gflop_per_launch': round(k['flops'] / k['n'] / 1e9, 3),
+                                'issued_bf16_tflops': round(3 * ach, 2), 'issued_frac': round(3 * ach / PEAK_BF16_TFLOPS, 4),
+                                'vs_fp32_peak_157.3': round(ach / PEAK_FP32_TFLOPS, 3),
+                                'share_of_gpu_time': round(k['ms'] / sum(v['ms'] for v in prof.values()), 3)}
+            line['kernel_time_ms_per_batch'] = {n: round(v['ms'], 3) for n, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log('timing the CPU oracle on one slice ...')
+        line['cpu_baseline'] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

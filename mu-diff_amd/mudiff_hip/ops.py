@@ -60,6 +60,46 @@ class View:
         return self.base.device
 
 
+class _Profile:
+    """Optional per-launch timing with HIP events on the launching stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.on = False
+        self.records = []
+
+    def enable(self):
+        self.on, self.records = True, []
+
+    def disable(self):
+        self.on = False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, flops, nbytes in self.records:
+            d = out.setdefault(name, dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
+            d['n'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += flops
+            d['bytes'] += nbytes
+        return out
+
+
+PROFILE = _Profile()
+
+
+def _launch(name, fn, *args, flops=0.0, nbytes=0.0):
+    if PROFILE.on:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        code = fn(*args)
+        e1.record()
+        PROFILE.records.append((name, e0, e1, flops, nbytes))
+    else:
+        code = fn(*args)
+    check(code, name)
+
+
 def _f32(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t
@@ -76,8 +116,8 @@ def posterior_sample(x01, x02, xt, noise, t, coef1, coef2, std_tab, out=None):
         assert x02.shape == xt.shape
     assert x01.shape == xt.shape == noise.shape and t.dtype == torch.int64 and t.numel() == B
     out = torch.empty_like(xt) if out is None else out
-    check(load().mud_posterior_sample(ptr(x01), ptr(x02), ptr(xt), ptr(noise), ptr(t.contiguous()), ptr(coef1), ptr(coef2),
-                                      ptr(std_tab), coef1.numel(), ptr(out), B, per, stream_ptr()), 'mud_posterior_sample')
+    _launch('posterior_sample', load().mud_posterior_sample, ptr(x01), ptr(x02), ptr(xt), ptr(noise), ptr(t.contiguous()), ptr(coef1), ptr(coef2),
+                                      ptr(std_tab), coef1.numel(), ptr(out), B, per, stream_ptr())
     return out
 
 
@@ -86,8 +126,8 @@ def q_sample(x, noise, t, toff, a_tab, s_tab):
     x, noise = _f32(x.contiguous()), _f32(noise.contiguous())
     B = x.shape[0]
     out = torch.empty_like(x)
-    check(load().mud_q_sample(ptr(x), ptr(noise), ptr(t.contiguous()), toff, ptr(a_tab), ptr(s_tab), a_tab.numel(), ptr(out), B,
-                              x[0].numel() if B else 0, stream_ptr()), 'mud_q_sample')
+    _launch('q_sample', load().mud_q_sample, ptr(x), ptr(noise), ptr(t.contiguous()), toff, ptr(a_tab), ptr(s_tab), a_tab.numel(), ptr(out), B,
+                              x[0].numel() if B else 0, stream_ptr())
     return out
 
 
@@ -95,8 +135,7 @@ def timestep_embedding(t, dim, max_positions=10000.0):
     require_gpu(t)
     assert t.dim() == 1 and t.dtype == torch.int64
     out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
-    check(load().mud_timestep_embedding(ptr(t.contiguous()), ptr(out), t.shape[0], dim, float(max_positions), stream_ptr()),
-          'mud_timestep_embedding')
+    _launch('timestep_embedding', load().mud_timestep_embedding, ptr(t.contiguous()), ptr(out), t.shape[0], dim, float(max_positions), stream_ptr())
     return out
 
 
@@ -104,7 +143,7 @@ def pixel_norm(z):
     require_gpu(z)
     z = _f32(z.contiguous())
     out = torch.empty_like(z)
-    check(load().mud_pixel_norm(ptr(z), ptr(out), z.shape[0], z.shape[1], stream_ptr()), 'mud_pixel_norm')
+    _launch('pixel_norm', load().mud_pixel_norm, ptr(z), ptr(out), z.shape[0], z.shape[1], stream_ptr())
     return out
 
 
@@ -115,8 +154,8 @@ def dense(x, W, bias, act_in=ACT_NONE, act_out=ACT_NONE):
     B, K = x.shape
     N = W.shape[0]
     out = torch.empty(B, N, device=x.device, dtype=torch.float32)
-    check(load().mud_dense(ptr(x), x.stride(0) if B > 1 else K, ptr(W), ptr(bias), ptr(out), N, B, K, N, act_in, act_out,
-                           stream_ptr()), 'mud_dense')
+    _launch('dense', load().mud_dense, ptr(x), x.stride(0) if B > 1 else K, ptr(W), ptr(bias), ptr(out), N, B, K, N, act_in, act_out,
+                           stream_ptr())
     return out
 
 
@@ -143,8 +182,8 @@ def gn_scale_shift(x: View, G, gamma=None, beta=None, eps=1e-6):
         if gamma.dim() == 2:
             assert gamma.shape[0] == x.B and gamma.stride(0) == beta.stride(0)
             bstride = gamma.stride(0)
-    check(lib.mud_gn_scale_shift(x.ptr, x.B, HW, x.C, x.ld, G, eps, ptr(gamma), ptr(beta), bstride, ptr(ss[0]), ptr(ss[1]), x.C,
-                                 None, ptr(ws), stream_ptr()), 'mud_gn_scale_shift')
+    _launch('gn_scale_shift', lib.mud_gn_scale_shift, x.ptr, x.B, HW, x.C, x.ld, G, eps, ptr(gamma), ptr(beta), bstride, ptr(ss[0]),
+            ptr(ss[1]), x.C, None, ptr(ws), stream_ptr(), nbytes=4.0 * x.npix * x.C)
     return ss[0], ss[1]
 
 
@@ -153,7 +192,7 @@ def channel_mean(x: View):
     HW = x.H * x.W
     ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, x.C))
     out = torch.empty(x.B, x.C, device=x.device, dtype=torch.float32)
-    check(lib.mud_channel_mean(x.ptr, x.B, HW, x.C, x.ld, ptr(out), x.C, ptr(ws), stream_ptr()), 'mud_channel_mean')
+    _launch('channel_mean', lib.mud_channel_mean, x.ptr, x.B, HW, x.C, x.ld, ptr(out), x.C, ptr(ws), stream_ptr(), nbytes=4.0 * x.npix * x.C)
     return out
 
 
@@ -164,8 +203,8 @@ def pack_weights(src, s_tap, s_ci, s_co, ks, Cin, Cout, nbatch=1, src_bstride=0,
     require_gpu(src)
     nbytes = lib.mud_packed_weight_bytes(ks, Cin, Cout)
     dst = torch.empty(nbatch, nbytes, device=src.device, dtype=torch.uint8)
-    check(lib.mud_pack_weights(C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch,
-                               ptr(dst), stream_ptr()), 'mud_pack_weights')
+    _launch('pack_weights', lib.mud_pack_weights, C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch,
+                               ptr(dst), stream_ptr())
     return dst
 
 
@@ -219,7 +258,10 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     a.out_scale, a.act = out_scale, act
     a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
-    check(fn(C.byref(a), stream_ptr()), 'mud_conv2d_mfma' if mfma else 'mud_conv2d_direct')
+    name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
+    flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks
+    nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * (2 if res is not None else 1)) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
+    _launch(name, fn, C.byref(a), stream_ptr(), flops=flops, nbytes=nbytes)
     return out
 
 
@@ -235,8 +277,7 @@ def upfirdn2d_planes(x, kernel, up, down, pad):
     Ho = (H * uy + py0 + py1 - kh) // dy + 1
     Wo = (W * ux + px0 + px1 - kw) // dx + 1
     out = torch.empty(N, Cc, Ho, Wo, device=x.device, dtype=torch.float32)
-    check(load().mud_upfirdn2d(ptr(xin), N * Cc, H, W, ptr(k), kh, kw, ux, uy, dx, dy, px0, px1, py0, py1, ptr(out), stream_ptr()),
-          'mud_upfirdn2d')
+    _launch('upfirdn2d', load().mud_upfirdn2d, ptr(xin), N * Cc, H, W, ptr(k), kh, kw, ux, uy, dx, dy, px0, px1, py0, py1, ptr(out), stream_ptr())
     return out.to(x.dtype)
 
 
@@ -254,28 +295,27 @@ def fir_nhwc(x: View, kernel2d, up, down, pad, pro=None, want_h=True, want_x=Fal
     if pro is not None:
         sc, sh, mode = pro
         ld = sc.stride(0)
-    check(load().mud_fir_nhwc(x.ptr, x.B, x.H, x.W, x.C, x.ld, k.ctypes.data_as(C.POINTER(C.c_float)), kh, kw, up, down, pad[0],
-                              pad[1], ptr(sc), ptr(sh), ld, mode, oh.ptr if oh else None, oh.ld if oh else 0,
-                              ox.ptr if ox else None, ox.ld if ox else 0, stream_ptr()), 'mud_fir_nhwc')
+    _launch('fir_nhwc', load().mud_fir_nhwc, x.ptr, x.B, x.H, x.W, x.C, x.ld, k.ctypes.data_as(C.POINTER(C.c_float)), kh, kw, up, down,
+            pad[0], pad[1], ptr(sc), ptr(sh), ld, mode, oh.ptr if oh else None, oh.ld if oh else 0, ox.ptr if ox else None,
+            ox.ld if ox else 0, stream_ptr(), nbytes=4.0 * x.C * (x.npix + x.B * Ho * Wo * (int(want_h) + int(want_x))))
     return oh, ox
 
 
 def softmax_rows_(s, n):
     """in-place softmax over the last axis of a contiguous [..., n] tensor."""
     rows = s.numel() // n
-    check(load().mud_softmax_rows(ptr(s), rows, n, n, stream_ptr()), 'mud_softmax_rows')
+    _launch('softmax_rows', load().mud_softmax_rows, ptr(s), rows, n, n, stream_ptr())
     return s
 
 
 def mul(a: View, b: View, out: View = None):
     out = View.empty(a.B, a.H, a.W, a.C, a.device) if out is None else out
-    check(load().mud_mul(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.npix, a.C, stream_ptr()), 'mud_mul')
+    _launch('mul', load().mud_mul, a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.npix, a.C, stream_ptr())
     return out
 
 
 def gate_mix(g: View, att: View, other: View, out: View):
-    check(load().mud_gate_mix(g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.npix, g.C, stream_ptr()),
-          'mud_gate_mix')
+    _launch('gate_mix', load().mud_gate_mix, g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.npix, g.C, stream_ptr())
     return out
 
 
