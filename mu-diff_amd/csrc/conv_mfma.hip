@@ -8,143 +8,212 @@
 //      lo*hi + hi*lo + hi*hi          (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)
 // i.e. ~2^-17 relative error per product at 16/3 = 5.3x the fp32-MFMA rate.
 //
-// Tiling (one 256-thread workgroup = 4 waves, one wave per SIMD):
-//   * output tile: 8 rows x 32 columns of pixels (ks=3) or 256 flat positions (ks=1) x 64 channels;
-//     wave w owns rows 2w, 2w+1 -> 2 (pixel) x 2 (channel) MFMA tiles of 32x32, 64 accumulator VGPRs.
-//   * K loop over chunks of 32 input channels.  Per chunk the block stages in LDS
-//       A: the (8+2)x(32+2) input halo tile, transformed ONCE on the way in (GroupNorm/AdaGN affine,
-//          SiLU, bf16 hi/lo split) and then reused by all 9 taps and all 64 output channels;
-//       B: the pre-packed, pre-split weight tile [tap][hi|lo][k16][64 co][16 ci] (linear copy).
-//     Both images keep 16 contiguous K values (32 B) per pixel/channel so that every MFMA operand is
-//     one ds_read_b128; the two 16-B halves of a row are swapped on rows with bit 3 set, which makes
-//     the 4x16-lane ds_read_b128 groups hit 16 distinct 16-B bank slots (conflict-free).
+// Structure (one 256-thread workgroup = 4 waves, template <KS, MT>):
+//   * output tile: (4*MT) rows x 32 columns of pixels (ks=3) or 128*MT flat positions (ks=1) x 64
+//     channels; wave w owns MT rows -> MT x 2 MFMA tiles of 32x32 (MT = 4: 128 accumulator regs).
+//   * A operand (activations): the (rows+2) x 34 halo tile of one 16-channel K chunk lives in LDS as
+//     two bf16 planes (hi, lo), 32 B per pixel, so every MFMA A fragment is one ds_read_b128 at a
+//     tap-shifted pixel; the two 16-B halves are swapped on pixels with bit 3 set (conflict-free
+//     b128 reads).  It is transformed ONCE on the way in (GroupNorm/AdaGN affine, SiLU, hi/lo split)
+//     and reused by 9 taps x 64 output channels.  Double-buffered: the raw fp32 values of chunk k+1
+//     are fetched into registers before the MFMAs of chunk k and written to the other LDS buffer
+//     after them -> one barrier per chunk, global latency hidden under the matrix work.
+//   * B operand (weights): pre-split, pre-packed on the host side of the ABI into exactly the MFMA
+//     fragment order, so a wave's B fragment is ONE fully coalesced 1 KiB global load (L2-resident,
+//     shared by every workgroup) straight into registers - no LDS, no barrier; fetched two taps ahead.
 //   * epilogue from the accumulators: + bias[co] + bias2[b,co] (time embedding) + residual, * scale,
 //     activation; each half-wave stores 32 consecutive channels (128 B) of one pixel.
+//   * workgroup ids are remapped so that the workgroups sharing an input tile (different output-channel
+//     tiles) and spatial neighbours run on the same XCD (shared L2).
 #include "mud_common.h"
+#include <stdlib.h>
 
-#define CM_TH 8
-#define CM_TW 32
 #define CM_BN 64
-#define CM_KC 32
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
+#define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
 
-template <int KS>
+template <int KS, int MT>
 struct CmGeo {
-  static constexpr int HALO = KS - 1;
-  static constexpr int PW = CM_TW + HALO;
-  static constexpr int P = (KS == 1) ? 256 : (CM_TH + HALO) * PW;
-  static constexpr int A_PLANE = P * 32;
-  static constexpr int A_BYTES = 4 * A_PLANE;               // [k16 half s][hi|lo]
-  static constexpr int B_BYTES = KS * KS * 4 * CM_BPLANE;   // [tap][hi|lo][s]
-  static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+  static constexpr int TAPS = KS * KS;
+  static constexpr int CH = (KS == 3) ? 1 : 2;          // k16 steps per LDS chunk
+  static constexpr int KCH = 16 * CH;                   // input channels per LDS chunk
+  static constexpr int ROWS = 4 * MT;
+  static constexpr int PW = 32 + KS - 1;
+  static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
+  static constexpr int PLANE = P * 32;                  // P pixels x 16 ch bf16
+  static constexpr int BUF = 2 * CH * PLANE;            // [k16 s][hi|lo]
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
+  static constexpr int ITEMS = P * Q;
+  static constexpr int NLOAD = (ITEMS + 255) / 256;
+  static constexpr int STEPS = TAPS * CH;               // MFMA steps (tap, s) per chunk
+  static constexpr int RING = (KS == 3) ? 3 : 2;        // B fragment register ring (prefetch distance RING-1)
 };
 
 __device__ __forceinline__ int cm_row_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
-template <int KS>
-__global__ __launch_bounds__(256) void k_conv_mfma(mud_conv_args a, int tiles_x, int kchunks) {
-  using G = CmGeo<KS>;
+__device__ __forceinline__ float cm_fast_silu(float v) {
+  // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): the result is rounded to bf16 hi+lo (2^-17) anyway
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
+                                                       unsigned nblocks) {
+  using G = CmGeo<KS, MT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;
-  char* sB = smem + G::A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, nt = blockIdx.y;
+
+  // ---- XCD-aware bijective remap: consecutive logical ids share an XCD (blocks i, i+8 are co-resident on one XCD)
+  unsigned lid;
+  {
+    const unsigned orig = blockIdx.x, xcd = orig & 7u, q = nblocks >> 3, rem = nblocks & 7u;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  }
+  const int nt = lid % ntiles;                  // output-channel tile fastest: sharers of one A tile are neighbours
+  const unsigned rest = lid / ntiles;
+  const int tile = rest % tiles_per_img;
+  const int b = rest / tiles_per_img;
+
   const int64_t HW = (int64_t)a.H * a.W;
   int ty0 = 0, tx0 = 0;
   int64_t flat0 = 0;
   if (KS == 3) {
-    ty0 = (blockIdx.x / tiles_x) * CM_TH;
-    tx0 = (blockIdx.x % tiles_x) * CM_TW;
+    ty0 = (tile / tiles_x) * G::ROWS;
+    tx0 = (tile % tiles_x) * 32;
   } else {
-    flat0 = (int64_t)blockIdx.x * 256;
+    flat0 = (int64_t)tile * G::P;
   }
   const float* xb = a.x + (int64_t)b * HW * a.ldx;
-  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * kchunks * G::B_BYTES;
+  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * k16s * (G::TAPS * CM_BSTEP) + r * 32 + hh * 16;
   const float* psc = a.pro_scale + (int64_t)b * a.pro_ld;
   const float* psh = a.pro_shift + (int64_t)b * a.pro_ld;
+  const int nchunks = (k16s + G::CH - 1) / G::CH;
 
-  f32x16 acc[2][2];
+  // ---- per-thread staging slots: pixel -> global element offset (or -1) and LDS byte offset, fixed for all chunks
+  const int q = tid % G::Q;                     // this thread's float4 (4 channels) inside a chunk
+  int goff[G::NLOAD], loff[G::NLOAD];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int j = 0; j < G::NLOAD; ++j) {
+    const int item = tid + j * 256;
+    const int p = item / G::Q;
+    bool valid = item < G::ITEMS;
+    int64_t g = 0;
+    if (KS == 3) {
+      const int py = p / G::PW, px = p - py * G::PW;
+      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+      valid = valid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      g = ((int64_t)gy * a.W + gx) * a.ldx;
+    } else {
+      const int64_t fp = flat0 + p;
+      valid = valid && fp < HW;
+      g = fp * a.ldx;
+    }
+    goff[j] = valid ? (int)g : -1;
+    loff[j] = (item < G::ITEMS) ? ((q >> 2) * 2 * G::PLANE + cm_row_off(p, (q & 3) >> 1) + (q & 1) * 8) : -1;
+  }
+
+  f32x4 raw[G::NLOAD];
+  auto fetch_a = [&](int chunk) {
+    const int c = chunk * G::KCH + q * 4;
+    const bool cvalid = c < a.Cin;
+#pragma unroll
+    for (int j = 0; j < G::NLOAD; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cvalid && goff[j] >= 0) v = *(const f32x4*)(xb + goff[j] + c);
+      raw[j] = v;
+    }
+  };
+  auto store_a = [&](int chunk, char* buf) {
+    const int c = chunk * G::KCH + q * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.pro_mode != MUD_PRO_NONE && c < a.Cin) {
+      sc = *(const f32x4*)(psc + c);
+      sh = *(const f32x4*)(psh + c);
+    }
+#pragma unroll
+    for (int j = 0; j < G::NLOAD; ++j) {
+      if (loff[j] < 0) continue;
+      f32x4 v = raw[j];
+      if (a.pro_mode != MUD_PRO_NONE && goff[j] >= 0) {     // zero padding stays zero
+        v = v * sc + sh;
+        if (a.pro_mode == MUD_PRO_AFFINE_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
+        }
+      }
+      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+      const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+      *(bf16x4*)(buf + loff[j]) = hi;
+      *(bf16x4*)(buf + loff[j] + G::PLANE) = lo;
+    }
+  };
+
+  // ---- B fragments: [step ring][n tile][hi|lo]
+  bf16x8 bfr[G::RING][2][2];
+  const int total_steps = k16s * G::TAPS;       // global step index = k16 * TAPS + tap
+  auto fetch_b = [&](int gstep, int slot) {
+    if (gstep >= total_steps) gstep = total_steps - 1;   // harmless re-read past the end
+    const char* p = wb + (int64_t)gstep * CM_BSTEP;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      bfr[slot][n][0] = *(const bf16x8*)(p + n * 1024);
+      bfr[slot][n][1] = *(const bf16x8*)(p + CM_BPLANE + n * 1024);
+    }
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  for (int kc = 0; kc < kchunks; ++kc) {
-    __syncthreads();
-    // ---- stage A: global fp32 -> prologue -> bf16 hi/lo -> LDS
-    for (int i = tid; i < G::P * 8; i += 256) {
-      const int p = i >> 3, q = i & 7;
-      const int c = kc * CM_KC + q * 4;
-      bool valid = c < a.Cin;
-      const float* src;
-      if (KS == 3) {
-        const int py = p / G::PW, px = p - py * G::PW;
-        const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-        valid = valid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        src = xb + ((int64_t)gy * a.W + gx) * a.ldx + c;
-      } else {
-        const int64_t fp = flat0 + p;
-        valid = valid && fp < HW;
-        src = xb + fp * a.ldx + c;
-      }
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
-        v = *(const f32x4*)src;
-        if (a.pro_mode != MUD_PRO_NONE) {
-          const f32x4 sc = *(const f32x4*)(psc + c), sh = *(const f32x4*)(psh + c);
+  // ---- prologue: chunk 0 into buffer 0, first B fragments
+  fetch_a(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = mud_prologue(v[j], sc[j], sh[j], a.pro_mode);
-        }
-      }
-      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-      const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-      const int off = (q >> 2) * 2 * G::A_PLANE + cm_row_off(p, (q & 3) >> 1) + (q & 1) * 8;
-      *(bf16x4*)(sA + off) = hi;
-      *(bf16x4*)(sA + off + G::A_PLANE) = lo;
-    }
-    // ---- stage B: the packed weight tile is already in LDS order
-    {
-      const uint4* src = (const uint4*)(wb + (int64_t)kc * G::B_BYTES);
-      for (int i = tid; i < G::B_BYTES / 16; i += 256) ((uint4*)sB)[i] = src[i];
-    }
-    __syncthreads();
-    // ---- MFMA: 9 taps x 2 k16 halves x (2x2 tiles) x 3 split products
+  for (int s = 0; s < G::RING - 1; ++s) fetch_b(s, s);
+  store_a(0, smem);
+  __syncthreads();
+
+  for (int kc = 0; kc < nchunks; ++kc) {
+    char* cur = smem + (kc & 1) * G::BUF;
+    char* nxt = smem + ((kc + 1) & 1) * G::BUF;
+    const bool more = kc + 1 < nchunks;
+    if (more) fetch_a(kc + 1);
 #pragma unroll
-    for (int tap = 0; tap < KS * KS; ++tap) {
+    for (int st = 0; st < G::STEPS; ++st) {
+      // step st of this chunk: (s, tap).  KS=3: CH=1 -> st = tap.  KS=1: TAPS=1 -> st = s.
+      const int s = (KS == 3) ? 0 : st;
+      const int tap = (KS == 3) ? st : 0;
       const int dy = tap / KS, dx = tap % KS;
+      const int gstep = (kc * G::CH + s) * G::TAPS + tap;
+      fetch_b(gstep + G::RING - 1, (st + G::RING - 1) % G::RING);
+      const int slot = st % G::RING;
+      if (kc * G::CH + s < k16s) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int p = (KS == 3) ? ((wave * 2 + m + dy) * G::PW + r + dx) : (wave * 64 + m * 32 + r);
-          const int off = s * 2 * G::A_PLANE + cm_row_off(p, hh);
-          ah[m] = *(const bf16x8*)(sA + off);
-          al[m] = *(const bf16x8*)(sA + off + G::A_PLANE);
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const int off = (tap * 4 + s) * CM_BPLANE + cm_row_off(n * 32 + r, hh);
-          bh[n] = *(const bf16x8*)(sB + off);
-          bl[n] = *(const bf16x8*)(sB + off + 2 * CM_BPLANE);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m) {
+          const int p = (KS == 3) ? ((wave * MT + m + dy) * G::PW + r + dx) : ((wave * MT + m) * 32 + r);
+          const int off = s * 2 * G::PLANE + cm_row_off(p, hh);
+          const bf16x8 ah = *(const bf16x8*)(cur + off);
+          const bf16x8 al = *(const bf16x8*)(cur + off + G::PLANE);
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[slot][n][0], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[slot][n][1], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[slot][n][0], acc[m][n], 0, 0, 0);
           }
+        }
       }
+      if (st == G::STEPS / 2 && more) store_a(kc + 1, nxt);   // chunk k+1's LDS image, written under the MFMA shadow
     }
+    __syncthreads();
   }
 
   // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int co = nt * CM_BN + n * 32 + r;
@@ -157,11 +226,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(mud_conv_args a, int tiles_x,
         int64_t opix;
         bool valid;
         if (KS == 3) {
-          const int gy = ty0 + wave * 2 + m, gx = tx0 + prow;
+          const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
           valid = gy < a.H && gx < a.W;
           opix = ((int64_t)b * a.H + gy) * a.W + gx;
         } else {
-          const int64_t fp = flat0 + wave * 64 + m * 32 + prow;
+          const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
           valid = fp < HW;
           opix = (int64_t)b * HW + fp;
         }
@@ -175,20 +244,22 @@ __global__ __launch_bounds__(256) void k_conv_mfma(mud_conv_args a, int tiles_x,
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight / B-operand packing: fp32 (arbitrary strides) -> [n tile][k chunk][tap][hi|lo][k16][64][16] bf16
+// weight / B-operand packing: fp32 (arbitrary strides) -> [n tile][k16 chunk][tap][hi|lo][64 co][16 ci] bf16
+// (exactly the order in which a wave's lanes consume MFMA B fragments: lane (r, h) of n-tile n reads the 16 B
+//  at co = 32n + r, ci = 8h..8h+7)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ src, int64_t s_tap, int64_t s_ci, int64_t s_co,
-                                                      int64_t src_bstride, int taps, int Cin, int Cout, int kchunks,
+                                                      int64_t src_bstride, int taps, int Cin, int Cout, int k16s,
                                                       int64_t units, char* __restrict__ dst, int64_t dst_bstride) {
   const int b = blockIdx.y;
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (int64_t)gridDim.x * blockDim.x) {
-    const int h2 = (int)(u & 1), co_l = (int)((u >> 1) & 63), s = (int)((u >> 7) & 1);
-    int64_t rest = u >> 8;
+    const int h2 = (int)(u & 1), co_l = (int)((u >> 1) & 63);
+    int64_t rest = u >> 7;
     const int tap = (int)(rest % taps);
     rest /= taps;
-    const int kc = (int)(rest % kchunks);
-    const int nt = (int)(rest / kchunks);
-    const int co = nt * CM_BN + co_l, ci0 = kc * CM_KC + s * 16 + h2 * 8;
+    const int kc = (int)(rest % k16s);
+    const int nt = (int)(rest / k16s);
+    const int co = nt * CM_BN + co_l, ci0 = kc * 16 + h2 * 8;
     bf16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -198,16 +269,15 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
       hi[j] = h;
       lo[j] = (__bf16)(v - (float)h);
     }
-    char* base = dst + (int64_t)b * dst_bstride + (((int64_t)nt * kchunks + kc) * taps + tap) * (4 * CM_BPLANE);
-    const int off = s * CM_BPLANE + cm_row_off(co_l, h2);
-    *(bf16x8*)(base + off) = hi;
-    *(bf16x8*)(base + off + 2 * CM_BPLANE) = lo;
+    char* base = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP + co_l * 32 + h2 * 16;
+    *(bf16x8*)base = hi;
+    *(bf16x8*)(base + CM_BPLANE) = lo;
   }
 }
 
 extern "C" int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout) {
   if ((ks != 1 && ks != 3) || Cin <= 0 || Cout <= 0) return -1;
-  return mud_cdiv(Cout, CM_BN) * mud_cdiv(Cin, CM_KC) * (int64_t)ks * ks * 4 * CM_BPLANE;
+  return mud_cdiv(Cout, CM_BN) * mud_cdiv(Cin, 16) * (int64_t)ks * ks * CM_BSTEP;
 }
 
 extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride, int ks,
@@ -215,39 +285,41 @@ extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, i
   MUD_REQUIRE(src && dst, "mud_pack_weights: null pointer");
   MUD_REQUIRE((ks == 1 || ks == 3) && Cin > 0 && Cout > 0 && nbatch >= 1 && nbatch <= 65535, "mud_pack_weights: bad sizes");
   MUD_REQUIRE(mud_aligned16(dst), "mud_pack_weights: dst must be 16-byte aligned");
-  const int kchunks = (int)mud_cdiv(Cin, CM_KC), ntiles = (int)mud_cdiv(Cout, CM_BN), taps = ks * ks;
-  const int64_t units = (int64_t)ntiles * kchunks * taps * 256;
+  const int k16s = (int)mud_cdiv(Cin, 16), ntiles = (int)mud_cdiv(Cout, CM_BN), taps = ks * ks;
+  const int64_t units = (int64_t)ntiles * k16s * taps * 128;
   int64_t blocks = mud_cdiv(units, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(k_pack_weights, dim3((int)blocks, nbatch), dim3(256), 0, (hipStream_t)stream, src, s_tap, s_ci, s_co,
-                     src_bstride, taps, Cin, Cout, kchunks, units, (char*)dst, mud_packed_weight_bytes(ks, Cin, Cout));
+                     src_bstride, taps, Cin, Cout, k16s, units, (char*)dst, mud_packed_weight_bytes(ks, Cin, Cout));
   MUD_CHECK_LAUNCH("mud_pack_weights");
   return MUD_OK;
 }
 
-template <int KS>
+template <int KS, int MT>
 static int cm_launch(const mud_conv_args& a, hipStream_t s) {
-  using G = CmGeo<KS>;
+  using G = CmGeo<KS, MT>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_mfma<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_mfma<KS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  const int kchunks = (int)mud_cdiv(a.Cin, CM_KC), ntiles = (int)mud_cdiv(a.Cout, CM_BN);
+  const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN);
   int tiles_x = 1;
   int64_t tiles;
   if (KS == 3) {
-    tiles_x = (int)mud_cdiv(a.W, CM_TW);
-    tiles = (int64_t)tiles_x * mud_cdiv(a.H, CM_TH);
+    tiles_x = (int)mud_cdiv(a.W, 32);
+    tiles = (int64_t)tiles_x * mud_cdiv(a.H, G::ROWS);
   } else {
-    tiles = mud_cdiv((int64_t)a.H * a.W, 256);
+    tiles = mud_cdiv((int64_t)a.H * a.W, G::P);
   }
-  MUD_REQUIRE(tiles <= 0x7fffffff && ntiles <= 65535 && a.B <= 65535, "mud_conv2d_mfma: grid too large");
-  hipLaunchKernelGGL((k_conv_mfma<KS>), dim3((unsigned)tiles, ntiles, a.B), dim3(256), G::LDS_BYTES, s, a, tiles_x, kchunks);
+  const int64_t nblocks = tiles * ntiles * a.B;
+  MUD_REQUIRE(nblocks <= 0x7fffffff, "mud_conv2d_mfma: grid too large");
+  hipLaunchKernelGGL((k_conv_mfma<KS, MT>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
+                     (unsigned)nblocks);
   MUD_CHECK_LAUNCH("mud_conv2d_mfma");
   return MUD_OK;
 }
@@ -259,6 +331,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE((a.ks == 1 || a.ks == 3) && a.stride == 1 && a.pad == a.ks / 2, "mud_conv2d_mfma: only ks in {1,3}, stride 1, pad ks/2 (got ks=%d stride=%d pad=%d)", a.ks, a.stride, a.pad);
   MUD_REQUIRE(a.B >= 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "mud_conv2d_mfma: bad sizes");
   MUD_REQUIRE(a.Cin % 4 == 0 && a.ldx % 4 == 0 && a.ldx >= a.Cin && mud_aligned16(a.x), "mud_conv2d_mfma: needs Cin%%4==0 (Cin=%d), ldx%%4==0 (ldx=%d), 16-byte aligned x", a.Cin, a.ldx);
+  MUD_REQUIRE((int64_t)a.H * a.W * a.ldx < 0x7fffffffLL, "mud_conv2d_mfma: one image must stay below 2^31 elements");
   MUD_REQUIRE(mud_aligned16(a.w) && a.w_bstride % 16 == 0, "mud_conv2d_mfma: packed weights must be 16-byte aligned");
   MUD_REQUIRE(a.ldo >= a.Cout && (!a.res || a.ldr >= a.Cout), "mud_conv2d_mfma: bad output/residual view");
   if (a.pro_mode != MUD_PRO_NONE) {
@@ -269,5 +342,22 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
     a.pro_ld = 0;
   }
   if (a.B == 0) return MUD_OK;
-  return a.ks == 3 ? cm_launch<3>(a, (hipStream_t)stream) : cm_launch<1>(a, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  // tile height by problem size: big tiles (more MFMA work per weight byte) once they still fill the 256 CUs
+  const int64_t ntiles = mud_cdiv(a.Cout, CM_BN);
+  static const int force_mt = getenv("MUD_CONV_MT") ? atoi(getenv("MUD_CONV_MT")) : 0;   // tuning knob
+  if (force_mt) {
+    if (a.ks == 3) return force_mt == 4 ? cm_launch<3, 4>(a, s) : force_mt == 2 ? cm_launch<3, 2>(a, s) : cm_launch<3, 1>(a, s);
+    return force_mt == 4 ? cm_launch<1, 4>(a, s) : force_mt == 2 ? cm_launch<1, 2>(a, s) : cm_launch<1, 1>(a, s);
+  }
+  // Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
+  // beats MT=4 (one workgroup per CU) by 15-40 % on every layer shape; MT=1 only when MT=2 cannot give 2 blocks/CU.
+  if (a.ks == 3) {
+    const int64_t blocks2 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * ntiles * a.B;
+    if (blocks2 >= 512 && a.H >= 8) return cm_launch<3, 2>(a, s);
+    return cm_launch<3, 1>(a, s);
+  }
+  const int64_t hw = (int64_t)a.H * a.W;
+  if (mud_cdiv(hw, 256) * ntiles * a.B >= 512) return cm_launch<1, 2>(a, s);
+  return cm_launch<1, 1>(a, s);
 }
