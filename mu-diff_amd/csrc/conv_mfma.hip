@@ -12,9 +12,9 @@
 //   * output tile: (4*MT) rows x 32 columns of pixels (ks=3) or 128*MT flat positions (ks=1) x 64
 //     channels; wave w owns MT rows -> MT x 2 MFMA tiles of 32x32 (MT = 4: 128 accumulator regs).
 //   * A operand (activations): the (rows+2) x 34 halo tile of one 16-channel K chunk lives in LDS as
-//     two bf16 planes (hi, lo), 32 B per pixel, so every MFMA A fragment is one ds_read_b128 at a
-//     tap-shifted pixel; the two 16-B halves are swapped on pixels with bit 3 set (conflict-free
-//     b128 reads).  It is transformed ONCE on the way in (GroupNorm/AdaGN affine, SiLU, hi/lo split)
+//     80-byte pixel records [hi 16 x bf16 | lo 16 x bf16 | 16 B pad], so every MFMA A fragment is one
+//     ds_read_b128 at base + (compile-time tap/row offset): the 80-B stride spreads the 16 lanes of a
+//     b128 read group over 16 distinct 16-B bank slots (conflict-free) with NO per-tap address maths.  It is transformed ONCE on the way in (GroupNorm/AdaGN affine, SiLU, hi/lo split)
 //     and reused by 9 taps x 64 output channels.  Double-buffered: the raw fp32 values of chunk k+1
 //     are fetched into registers before the MFMAs of chunk k and written to the other LDS buffer
 //     after them -> one barrier per chunk, global latency hidden under the matrix work.
@@ -31,6 +31,7 @@
 #define CM_BN 64
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
+#define CM_PIX 80                // LDS bytes per pixel record of the A tile
 
 template <int KS, int MT>
 struct CmGeo {
@@ -40,8 +41,8 @@ struct CmGeo {
   static constexpr int ROWS = 4 * MT;
   static constexpr int PW = 32 + KS - 1;
   static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
-  static constexpr int PLANE = P * 32;                  // P pixels x 16 ch bf16
-  static constexpr int BUF = 2 * CH * PLANE;            // [k16 s][hi|lo]
+  static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
+  static constexpr int BUF = CH * PLANE;                // [k16 s]
   static constexpr int LDS_BYTES = 2 * BUF;
   static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
   static constexpr int ITEMS = P * Q;
@@ -50,14 +51,13 @@ struct CmGeo {
   static constexpr int RING = (KS == 3) ? 3 : 2;        // B fragment register ring (prefetch distance RING-1)
 };
 
-__device__ __forceinline__ int cm_row_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
 __device__ __forceinline__ float cm_fast_silu(float v) {
   // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): the result is rounded to bf16 hi+lo (2^-17) anyway
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
-template <int KS, int MT>
+template <int KS, int MT, int PRO>
 __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
                                                        unsigned nblocks) {
   using G = CmGeo<KS, MT>;
@@ -90,62 +90,63 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   const float* psh = a.pro_shift + (int64_t)b * a.pro_ld;
   const int nchunks = (k16s + G::CH - 1) / G::CH;
 
-  // ---- per-thread staging slots: pixel -> global element offset (or -1) and LDS byte offset, fixed for all chunks
+  // ---- per-thread staging slots: pixel -> global element offset and LDS byte offset, fixed for all chunks.
+  // Everything below is branch-free: padding pixels load a clamped (valid) address and are zeroed by a 0/1
+  // mask; slots past the tile wrap around and redo another thread's item (identical value, same address).
   const int q = tid % G::Q;                     // this thread's float4 (4 channels) inside a chunk
   int goff[G::NLOAD], loff[G::NLOAD];
+  unsigned vmask = 0;                           // bit j: slot j is a real (non-padding) pixel
 #pragma unroll
   for (int j = 0; j < G::NLOAD; ++j) {
-    const int item = tid + j * 256;
+    const int item = (tid + j * 256) % G::ITEMS;   // 256 % Q == 0 and ITEMS % Q == 0: q is preserved
     const int p = item / G::Q;
-    bool valid = item < G::ITEMS;
-    int64_t g = 0;
+    bool valid;
+    int64_t g;
     if (KS == 3) {
       const int py = p / G::PW, px = p - py * G::PW;
       const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-      valid = valid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      valid = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       g = ((int64_t)gy * a.W + gx) * a.ldx;
     } else {
       const int64_t fp = flat0 + p;
-      valid = valid && fp < HW;
+      valid = fp < HW;
       g = fp * a.ldx;
     }
-    goff[j] = valid ? (int)g : -1;
-    loff[j] = (item < G::ITEMS) ? ((q >> 2) * 2 * G::PLANE + cm_row_off(p, (q & 3) >> 1) + (q & 1) * 8) : -1;
+    goff[j] = valid ? (int)g : 0;
+    vmask |= (valid ? 1u : 0u) << j;
+    loff[j] = (q >> 2) * G::PLANE + p * CM_PIX + (q & 3) * 8;
   }
 
   f32x4 raw[G::NLOAD];
+  f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
   auto fetch_a = [&](int chunk) {
-    const int c = chunk * G::KCH + q * 4;
-    const bool cvalid = c < a.Cin;
+    int c = chunk * G::KCH + q * 4;
+    c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
-    for (int j = 0; j < G::NLOAD; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cvalid && goff[j] >= 0) v = *(const f32x4*)(xb + goff[j] + c);
-      raw[j] = v;
+    for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
+    if (PRO != MUD_PRO_NONE) {
+      psc_r = *(const f32x4*)(psc + c);
+      psh_r = *(const f32x4*)(psh + c);
     }
   };
   auto store_a = [&](int chunk, char* buf) {
-    const int c = chunk * G::KCH + q * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (a.pro_mode != MUD_PRO_NONE && c < a.Cin) {
-      sc = *(const f32x4*)(psc + c);
-      sh = *(const f32x4*)(psh + c);
-    }
+    const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
-      if (loff[j] < 0) continue;
       f32x4 v = raw[j];
-      if (a.pro_mode != MUD_PRO_NONE && goff[j] >= 0) {     // zero padding stays zero
-        v = v * sc + sh;
-        if (a.pro_mode == MUD_PRO_AFFINE_SILU) {
+      if (PRO != MUD_PRO_NONE) {
+        v = v * psc_r + psh_r;
+        if (PRO == MUD_PRO_AFFINE_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
         }
       }
+      const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
+      v = v * keep;
       const bf16x4 hi = __builtin_convertvector(v, bf16x4);
       const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
       *(bf16x4*)(buf + loff[j]) = hi;
-      *(bf16x4*)(buf + loff[j] + G::PLANE) = lo;
+      *(bf16x4*)(buf + loff[j] + 32) = lo;
     }
   };
 
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
     }
   };
 
+  const int lane_a = ((KS == 3) ? (wave * MT * G::PW + r) : (wave * MT * 32 + r)) * CM_PIX + hh * 16;
   f32x16 acc[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -194,10 +196,10 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
       if (kc * G::CH + s < k16s) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const int p = (KS == 3) ? ((wave * MT + m + dy) * G::PW + r + dx) : ((wave * MT + m) * 32 + r);
-          const int off = s * 2 * G::PLANE + cm_row_off(p, hh);
-          const bf16x8 ah = *(const bf16x8*)(cur + off);
-          const bf16x8 al = *(const bf16x8*)(cur + off + G::PLANE);
+          // lane base (wave row, column r, k half hh) + compile-time (m, tap, s) offset
+          const int off = s * G::PLANE + ((KS == 3) ? ((m + dy) * G::PW + dx) : (m * 32)) * CM_PIX;
+          const bf16x8 ah = *(const bf16x8*)(cur + lane_a + off);
+          const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[slot][n][0], acc[m][n], 0, 0, 0);
@@ -295,12 +297,12 @@ extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, i
   return MUD_OK;
 }
 
-template <int KS, int MT>
-static int cm_launch(const mud_conv_args& a, hipStream_t s) {
+template <int KS, int MT, int PRO>
+static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   using G = CmGeo<KS, MT>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_mfma<KS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_mfma<KS, MT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
@@ -318,10 +320,19 @@ static int cm_launch(const mud_conv_args& a, hipStream_t s) {
   }
   const int64_t nblocks = tiles * ntiles * a.B;
   MUD_REQUIRE(nblocks <= 0x7fffffff, "mud_conv2d_mfma: grid too large");
-  hipLaunchKernelGGL((k_conv_mfma<KS, MT>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
+  hipLaunchKernelGGL((k_conv_mfma<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
                      (unsigned)nblocks);
   MUD_CHECK_LAUNCH("mud_conv2d_mfma");
   return MUD_OK;
+}
+
+template <int KS, int MT>
+static int cm_launch(const mud_conv_args& a, hipStream_t s) {
+  switch (a.pro_mode) {
+    case MUD_PRO_NONE: return cm_launch_pro<KS, MT, MUD_PRO_NONE>(a, s);
+    case MUD_PRO_AFFINE: return cm_launch_pro<KS, MT, MUD_PRO_AFFINE>(a, s);
+    default: return cm_launch_pro<KS, MT, MUD_PRO_AFFINE_SILU>(a, s);
+  }
 }
 
 extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
