@@ -59,15 +59,9 @@ def build_models(cfg, dev, rank, world):
     g1, g2 = g1.to(dev).eval(), g2.to(dev).eval()
     if world > 1:
         # parameters live on rank 0 (checkpoint reader); one flattened RCCL broadcast per generator over xGMI
-        import torch.distributed as dist
-        for m in (g1, g2):
-            params = [p.data for p in m.parameters()]
-            flat = torch.cat([p.reshape(-1) for p in params])
-            dist.broadcast(flat, src=0)
-            off = 0
-            for p in params:
-                p.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+        from mudiff_hip.distributed import broadcast_parameters
+        broadcast_parameters(g1, src=0)
+        broadcast_parameters(g2, src=0)
     return g1, g2
 
 
@@ -165,11 +159,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from mudiff_hip.distributed import max_over_ranks
+    dt = max_over_ranks(dt, dev)
 
     slices = world * B * K
     value = slices / dt
