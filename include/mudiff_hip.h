@@ -76,6 +76,11 @@ int mud_gn_scale_shift(const float* x, int B, int64_t HW, int C, int ld, int G, 
                        const float* gamma, const float* beta, int64_t g_bstride,
                        float* scale, float* shift, int ld_ss, float* mean_rstd /* [B,G,2] or NULL */,
                        void* ws, void* stream);
+/* Same result from per-channel (sum, sumsq) already accumulated by the producer's epilogue
+ * (mud_conv_args.stats, mud_gate_mix): sums[(b*sums_ld + c)*2 + {0,1}], `count` = pixels per channel. */
+int mud_gn_scale_shift_from_sums(const double* sums, int sums_ld, int B, int C, int G, double count, float eps,
+                                 const float* gamma, const float* beta, int64_t g_bstride,
+                                 float* scale, float* shift, int ld_ss, void* stream);
 /* out[b,c] = mean over pixels (nn.AdaptiveAvgPool2d(1), layerspp.py:473,491). ws as above with G=C. */
 int mud_channel_mean(const float* x, int B, int64_t HW, int C, int ld, float* out, int ldo, void* ws, void* stream);
 
@@ -93,6 +98,10 @@ typedef struct mud_conv_args {
   const float* res; int ldr;                     /* residual view [B,Ho,Wo,Cout] or NULL             */
   float out_scale; int act;                      /* out = act((acc+bias+bias2+res)*out_scale)        */
   float* out; int Cout, ldo;                     /* output view [B,Ho,Wo,Cout]                       */
+  double* stats; int stats_ld;                   /* optional: per-(b, channel) running (sum, sum of   */
+                                                 /* squares) of the STORED outputs, stats[(b*stats_ld */
+                                                 /* + co)*2 + {0,1}] += ... (fp64 atomics); lets the   */
+                                                 /* next GroupNorm skip its pass over the tensor       */
 } mud_conv_args;
 
 /* Exact fp32 direct convolution (FMA chain per output), any ks/stride/pad/Cin/Cout.
@@ -130,9 +139,9 @@ int mud_fir_nhwc(const float* x, int B, int H, int W, int C, int ldx, const floa
 /* ---- attention pieces (layerspp.py:118-122) and the G2 feature fusion (…feat.py:769-788) */
 int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* stream);          /* in place */
 int mud_mul(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t npix, int C, void* stream);
-/* out = g*att + (1-g)*other */
+/* out = g*att + (1-g)*other; views are [B, hw, C]; optional per-channel stats of `out` as in mud_conv_args */
 int mud_gate_mix(const float* g, int ldg, const float* att, int lda, const float* other, int ldb,
-                 float* out, int ldo, int64_t npix, int C, void* stream);
+                 float* out, int ldo, int B, int64_t hw, int C, double* stats, int stats_ld, void* stream);
 
 #ifdef __cplusplus
 }

@@ -231,9 +231,10 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
             d['c2'] = ConvParam(self.Conv_2)
         return d
 
-    def run(self, x: View, style0, style1, tbias, out: View = None):
+    def run(self, x: View, style0, style1, tbias, out: View = None, arena=None):
         """style0 [B,2*in_ch] / style1 [B,2*out_ch]: outputs of GroupNorm_{0,1}.style(zemb);
-        tbias [B,out_ch] or None: Dense_0(silu(temb))."""
+        tbias [B,out_ch] or None: Dense_0(silu(temb)).  With an `arena`, Conv_0's epilogue also accumulates
+        the GroupNorm_1 statistics (and `x.stats`, if its producer filled them, replaces the GroupNorm_0 pass)."""
         if self.dropout and self.training:
             raise NotImplementedError('dropout > 0 in training mode is not part of the inference path')
         p = self.prepared()
@@ -241,10 +242,10 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         if self.up or self.down:
             kk, up, down, pad = up_or_down_sampling.fir_params('up' if self.up else 'down', self.fir_kernel)
             h_in, x_skip = ops.fir_nhwc(x, kk, up, down, pad, pro=(sc0, sh0, PRO_AFFINE_SILU), want_h=True, want_x=True)
-            h = p['c0'](h_in, bias2=tbias)
+            h = p['c0'](h_in, bias2=tbias, arena=arena)
         else:
             x_skip = x
-            h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias)
+            h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena)
         sc1, sh1 = self.GroupNorm_1.scale_shift(h, style1)
         if 'c2' in p:
             x_skip = p['c2'](x_skip)
@@ -272,9 +273,9 @@ class ConvFeatBlock(nn.Module, _Prepared):
     def _prepare(self):
         return dict(c1=ConvParam(self.conv1), c2=ConvParam(self.conv2))
 
-    def run(self, x: View, out: View = None):
+    def run(self, x: View, out: View = None, arena=None):
         p = self.prepared()
-        h = p['c1'](x)
+        h = p['c1'](x, arena=arena)
         sc, sh = self.group_norm.scale_shift(h)
         return p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU), out=out)
 
@@ -295,9 +296,9 @@ class ConvBlock(nn.Module, _Prepared):
     def _prepare(self):
         return dict(c1=ConvParam(self.conv1), c2=ConvParam(self.conv2))
 
-    def run(self, x: View, style_out, out: View = None):
+    def run(self, x: View, style_out, out: View = None, arena=None):
         p = self.prepared()
-        h = p['c1'](x)
+        h = p['c1'](x, arena=arena)
         sc, sh = self.group_norm.scale_shift(h, style_out)
         return p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU), out=out)
 
@@ -322,9 +323,9 @@ class ConvBlock_GAP(nn.Module, _Prepared):
     def _prepare(self):
         return dict(c1=ConvParam(self.conv1), c2=ConvParam(self.conv2))
 
-    def run(self, x: View):
+    def run(self, x: View, arena=None):
         p = self.prepared()
-        h = p['c1'](x)
+        h = p['c1'](x, arena=arena)
         sc, sh = self.group_norm.scale_shift(h)
         h = p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU))
         gap = ops.channel_mean(h)

@@ -236,7 +236,7 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             v = View((2 * v.base - 1.).contiguous(), v.B, v.H, v.W, v.C)
         return v
 
-    def _make_buffers(self, B, H, W, dev):
+    def _make_buffers(self, B, H, W, dev, arena=None):
         """U-Net concatenation buffers.  Skip k (the k-th tensor pushed on the down path) is popped by
         up-block j = n_skips-1-k, whose input is cat([h, skip_k]) (reference :383).  Each up-block gets
         ONE buffer [B,H,W,Ch+Cs]; the producer of h and the producer of skip_k write straight into
@@ -260,10 +260,10 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             m = mods[e['idx']]
             cs = self._hs_channels[n_skips - 1 - j]
             sh_, sw_ = sizes[n_skips - 1 - j]
-            bufs.append((View.empty(B, sh_, sw_, m.in_ch, dev), m.in_ch - cs, cs))
+            bufs.append((View.empty(B, sh_, sw_, m.in_ch, dev, arena), m.in_ch - cs, cs))
         return trunk, bufs
 
-    def _trunk(self, p, trunk, bufs, x_img: View, temb, zemb):
+    def _trunk(self, p, trunk, bufs, x_img: View, temb, zemb, arena=None):
         """Down / mid / up path (reference :335-447, identical for both generators).  The head feature
         map (skip 0) has already been written into bufs[-1]'s skip slot by the caller."""
         mods = self.all_modules
@@ -275,7 +275,10 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         def res(e, x, out=None):
             o0, o1, o2, d0 = p['offs'][e['idx']]
             m = mods[e['idx']]
-            return m.run(x, styles[:, o0:o1], styles[:, o1:o2], tb_all[:, d0:d0 + m.out_ch], out=out)
+            if out is None:       # block output consumed by another GroupNorm (mid blocks, attention, upsample blocks, tail)
+                out = View.empty(x.B, x.H * (2 if m.up else 1) // (2 if m.down else 1), x.W * (2 if m.up else 1) // (2 if m.down else 1),
+                                 m.out_ch, x.device, arena)
+            return m.run(x, styles[:, o0:o1], styles[:, o1:o2], tb_all[:, d0:d0 + m.out_ch], out=out, arena=arena)
 
         def skip_slot(k):
             buf, ch, cs = bufs[n_skips - 1 - k]
@@ -314,7 +317,7 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             elif kind == 'res' and stage == 'mid':
                 h = res(e, h, out=None if nxt_is(i, 'attn', 'mid') else h_slot(0))
             elif kind == 'attn':
-                h = mods[e['idx']].run(h)
+                h = mods[e['idx']].run(h, out=View.empty(h.B, h.H, h.W, h.C, h.device, arena))
             elif kind == 'res' and stage == 'up':
                 buf, ch, cs = bufs[up_j]
                 assert h.base is buf.base and skips[-1].base is buf.base, 'concat slot bookkeeping broke'
@@ -348,11 +351,12 @@ class NCSNpp(_NCSNppBase):
             xv = self._prep_image(x)
             imgs = [xv] + [View.from_nchw(c.detach()) for c in (cond1, cond2, cond3)]
             nf = self.nf
-            trunk, bufs = self._make_buffers(B, H, W, xv.device)
+            arena = ops.StatsArena(xv.device)
+            trunk, bufs = self._make_buffers(B, H, W, xv.device, arena)
             hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
             for j, (e, img) in enumerate(zip([e for e in self._plan if e['kind'] == 'feat'], imgs)):
-                mods[e['idx']].run(img, out=hs0.slice(j * nf, nf))
-            return self._trunk(p, trunk, bufs, xv, temb, zemb)
+                mods[e['idx']].run(img, out=hs0.slice(j * nf, nf), arena=arena)
+            return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)
 
 
 @utils.register_model(name='ncsnpp_adaptive')
@@ -373,18 +377,19 @@ class NCSNpp_adaptive(_NCSNppBase):
             e_gap = next(e for e in self._plan if e['kind'] == 'gap')
             e_feat = next(e for e in self._plan if e['kind'] == 'feat')
             e_ada = [e for e in self._plan if e['kind'] == 'ada']
-            pseudo_weight = mods[e_gap['idx']].run(View.from_nchw(pseudo_target.detach().contiguous()))   # [B,256]
-            trunk, bufs = self._make_buffers(B, H, W, dev)
+            arena = ops.StatsArena(dev)
+            pseudo_weight = mods[e_gap['idx']].run(View.from_nchw(pseudo_target.detach().contiguous()), arena=arena)   # [B,256]
+            trunk, bufs = self._make_buffers(B, H, W, dev, arena)
             hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
-            mods[e_feat['idx']].run(xv, out=hs0.slice(0, nf))
+            mods[e_feat['idx']].run(xv, out=hs0.slice(0, nf), arena=arena)
             ada_styles = ops.dense(pseudo_weight, p['ada_w'], p['ada_b'])                                  # [B, 3*2nf]
             cat = View.empty(B, H, W, 3 * nf, dev)
             for j, (e, c) in enumerate(zip(e_ada, (cond1, cond2, cond3))):
-                mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf))
+                mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf), arena=arena)
             # six sigmoid gate convs share their input: one conv with 6*nf output channels (reference :769-776)
             gates = ops.conv(cat, p['gates_w'], 3, 6 * nf, mfma=p['gates_mfma'], bias=p['gates_b'], act=ACT_SIGMOID)
             for j, (a, b_) in enumerate(((0, 1), (1, 2), (2, 0))):      # (c1,c2), (c2,c3), (c3,c1)  (reference :778-788)
                 g1, g2 = gates.slice(2 * j * nf, nf), gates.slice((2 * j + 1) * nf, nf)
                 att = p['fw'][j](ops.mul(g1, cat.slice(a * nf, nf)))
                 ops.gate_mix(g2, att, cat.slice(b_ * nf, nf), hs0.slice((j + 1) * nf, nf))
-            return self._trunk(p, trunk, bufs, xv, temb, zemb)
+            return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)

@@ -10,14 +10,27 @@
 
 template <int VO, int VI>
 __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, int Wo, int co_groups) {
-  const int64_t total = (int64_t)a.B * Ho * Wo * co_groups;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* st_lds = (float*)smem_raw;             // [Cout][2] per-channel (sum, sumsq) of this block's outputs
+  const int b = blockIdx.y;
+  if (a.stats) {
+    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) st_lds[i] = 0.f;
+    __syncthreads();
+  }
+  const int64_t total = (int64_t)Ho * Wo * co_groups;
+  // loop stride = a multiple of co_groups, so a thread keeps its output-channel group and can fold the
+  // statistics of all its outputs in registers (threads past the last whole multiple sit out)
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (nthreads / co_groups) * co_groups;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float ssum[VO], ssq[VO];
+#pragma unroll
+  for (int j = 0; j < VO; ++j) ssum[j] = ssq[j] = 0.f;
+  for (int64_t idx = first; first < stride && idx < total; idx += stride) {
     const int cg = (int)(idx % co_groups);
     int64_t p = idx / co_groups;
     const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+    const int oy = (int)(p / Wo);
     const int co = cg * VO;
     float acc[VO];
 #pragma unroll
@@ -64,6 +77,24 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
     float* op = a.out + opix * a.ldo + co;
     if (VO == 4) *(f32x4*)op = *(f32x4*)acc;
     else op[0] = acc[0];
+#pragma unroll
+    for (int j = 0; j < VO; ++j) {
+      ssum[j] += acc[j];
+      ssq[j] += acc[j] * acc[j];
+    }
+  }
+  if (a.stats) {
+    if (first < stride && first < total) {
+      const int co = (int)(first % co_groups) * VO;
+#pragma unroll
+      for (int j = 0; j < VO; ++j) {
+        atomicAdd(&st_lds[(co + j) * 2], ssum[j]);
+        atomicAdd(&st_lds[(co + j) * 2 + 1], ssq[j]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256)
+      atomicAdd(a.stats + ((int64_t)b * a.stats_ld + (i >> 1)) * 2 + (i & 1), (double)st_lds[i]);
   }
 }
 
@@ -82,15 +113,19 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   const bool vo4 = a.Cout % 4 == 0 && a.ldo % 4 == 0 && mud_aligned16(a.out) && mud_aligned16(a.w) && (a.w_bstride % 16 == 0);
   const bool vi4 = a.Cin % 4 == 0 && a.ldx % 4 == 0 && mud_aligned16(a.x);
   const int co_groups = vo4 ? a.Cout / 4 : a.Cout;
-  const int64_t total = (int64_t)a.B * Ho * Wo * co_groups;
-  int64_t blocks = mud_cdiv(total, 256);
+  const int64_t total = (int64_t)Ho * Wo * co_groups;
+  int64_t blocks = mud_cdiv(total, 256 * (a.stats ? 8 : 1));   // several outputs per thread when the block folds statistics
   if (blocks > 256 * 32) blocks = 256 * 32;
+  while (blocks * 256 < co_groups) ++blocks;                   // the loop stride (a multiple of co_groups) must be positive
+  MUD_REQUIRE(a.B <= 65535, "mud_conv2d_direct: B too large");
+  MUD_REQUIRE(!a.stats || (a.stats_ld >= a.Cout && a.Cout <= 8192), "mud_conv2d_direct: bad stats view");
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((int)blocks), block(256);
-  if (vo4 && vi4) hipLaunchKernelGGL((k_conv_direct<4, 4>), grid, block, 0, s, a, Ho, Wo, co_groups);
-  else if (vo4) hipLaunchKernelGGL((k_conv_direct<4, 1>), grid, block, 0, s, a, Ho, Wo, co_groups);
-  else if (vi4) hipLaunchKernelGGL((k_conv_direct<1, 4>), grid, block, 0, s, a, Ho, Wo, co_groups);
-  else hipLaunchKernelGGL((k_conv_direct<1, 1>), grid, block, 0, s, a, Ho, Wo, co_groups);
+  dim3 grid((int)blocks, a.B), block(256);
+  const size_t lds = a.stats ? 2 * a.Cout * sizeof(float) : 0;
+  if (vo4 && vi4) hipLaunchKernelGGL((k_conv_direct<4, 4>), grid, block, lds, s, a, Ho, Wo, co_groups);
+  else if (vo4) hipLaunchKernelGGL((k_conv_direct<4, 1>), grid, block, lds, s, a, Ho, Wo, co_groups);
+  else if (vi4) hipLaunchKernelGGL((k_conv_direct<1, 4>), grid, block, lds, s, a, Ho, Wo, co_groups);
+  else hipLaunchKernelGGL((k_conv_direct<1, 1>), grid, block, lds, s, a, Ho, Wo, co_groups);
   MUD_CHECK_LAUNCH("mud_conv2d_direct");
   return MUD_OK;
 }

@@ -214,14 +214,16 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   }
 
   // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]
+  float* st_lds = (float*)smem;                 // [wave][64 ch][2] per-channel (sum, sumsq) of this block's outputs
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int n = 0; n < 2; ++n) {
+    const int co = nt * CM_BN + n * 32 + r;
+    const bool cok = co < a.Cout;
+    float badd = (a.bias && cok) ? a.bias[co] : 0.f;
+    if (a.bias2 && cok) badd += a.bias2[(int64_t)b * a.bias2_ld + co];
+    float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int co = nt * CM_BN + n * 32 + r;
-      if (co >= a.Cout) continue;
-      float badd = a.bias ? a.bias[co] : 0.f;
-      if (a.bias2) badd += a.bias2[(int64_t)b * a.bias2_ld + co];
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int prow = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
@@ -236,10 +238,33 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
           valid = fp < HW;
           opix = (int64_t)b * HW + fp;
         }
-        if (!valid) continue;
-        float v = acc[m][n][reg] + badd;
-        if (a.res) v += a.res[opix * a.ldr + co];
-        a.out[opix * a.ldo + co] = mud_act(v * a.out_scale, a.act);
+        if (valid && cok) {
+          float v = acc[m][n][reg] + badd;
+          if (a.res) v += a.res[opix * a.ldr + co];
+          v = mud_act(v * a.out_scale, a.act);
+          a.out[opix * a.ldo + co] = v;
+          ssum += v;
+          ssq += v * v;
+        }
+      }
+    }
+    if (a.stats) {                              // wave-uniform
+      ssum += __shfl_xor(ssum, 32, 64);         // the two half-waves hold the same channel
+      ssq += __shfl_xor(ssq, 32, 64);
+      if (hh == 0) {
+        st_lds[(wave * 64 + n * 32 + r) * 2] = ssum;
+        st_lds[(wave * 64 + n * 32 + r) * 2 + 1] = ssq;
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();                            // (the main loop ended with a barrier: the A buffers are dead)
+    if (tid < 128) {
+      const int ch = tid >> 1, k = tid & 1, co = nt * CM_BN + ch;
+      if (co < a.Cout) {
+        const float t = (st_lds[(0 * 64 + ch) * 2 + k] + st_lds[(1 * 64 + ch) * 2 + k]) +
+                        (st_lds[(2 * 64 + ch) * 2 + k] + st_lds[(3 * 64 + ch) * 2 + k]);
+        atomicAdd(a.stats + ((int64_t)b * a.stats_ld + co) * 2 + k, (double)t);
       }
     }
   }
@@ -345,6 +370,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE((int64_t)a.H * a.W * a.ldx < 0x7fffffffLL, "mud_conv2d_mfma: one image must stay below 2^31 elements");
   MUD_REQUIRE(mud_aligned16(a.w) && a.w_bstride % 16 == 0, "mud_conv2d_mfma: packed weights must be 16-byte aligned");
   MUD_REQUIRE(a.ldo >= a.Cout && (!a.res || a.ldr >= a.Cout), "mud_conv2d_mfma: bad output/residual view");
+  MUD_REQUIRE(!a.stats || a.stats_ld >= a.Cout, "mud_conv2d_mfma: bad stats view");
   if (a.pro_mode != MUD_PRO_NONE) {
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),
                 "mud_conv2d_mfma: prologue arrays missing or misaligned");

@@ -185,14 +185,26 @@ extern "C" int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* str
 // ------------------------------------------------------------------------------------------------
 // G2 feature fusion elementwise pieces (ncsnpp_generator_adagn_feat.py:778-788)
 // ------------------------------------------------------------------------------------------------
-template <int MODE>  // 0: a*b   1: g*att + (1-g)*other
+template <int MODE>  // 0: a*b   1: g*att + (1-g)*other (+ optional per-channel statistics of the result)
 __global__ __launch_bounds__(256) void k_ew3(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
                                              const float* __restrict__ c, int ldc, float* __restrict__ out, int ldo,
-                                             int64_t npix, int C4) {
-  const int64_t total = npix * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = i / C4;
-    const int q = (int)(i % C4) * 4;
+                                             int64_t hw, int C4, double* __restrict__ stats, int stats_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* st_lds = (float*)smem_raw;             // [C][2]
+  const int bi = blockIdx.y;
+  if (stats) {
+    for (int i = threadIdx.x; i < 8 * C4; i += 256) st_lds[i] = 0.f;
+    __syncthreads();
+  }
+  const int64_t total = hw * C4, base = (int64_t)bi * hw;
+  // a thread keeps the same 4 channels over its strided loop when 256 % C4 == 0 or the stride is a multiple of C4
+  f32x4 ls = {0.f, 0.f, 0.f, 0.f}, lq = {0.f, 0.f, 0.f, 0.f};
+  const int64_t stride = ((int64_t)gridDim.x * blockDim.x / C4) * C4;   // multiple of C4: channel quad is loop-invariant
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(first % C4) * 4;
+  const bool active = first < stride;            // threads past the last whole multiple of C4 would duplicate work
+  for (int64_t i = first; active && i < total; i += stride) {
+    const int64_t p = base + i / C4;
     const f32x4 va = *(const f32x4*)(a + p * lda + q);
     const f32x4 vb = *(const f32x4*)(b + p * ldb + q);
     f32x4 o;
@@ -202,6 +214,20 @@ __global__ __launch_bounds__(256) void k_ew3(const float* __restrict__ a, int ld
       o = va * vb + (1.0f - va) * vc;
     }
     *(f32x4*)(out + p * ldo + q) = o;
+    ls += o;
+    lq += o * o;
+  }
+  if (stats) {
+    if (active && first < total) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(&st_lds[(q + j) * 2], ls[j]);
+        atomicAdd(&st_lds[(q + j) * 2 + 1], lq[j]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * C4; i += 256)
+      atomicAdd(stats + ((int64_t)bi * stats_ld + (i >> 1)) * 2 + (i & 1), (double)st_lds[i]);
   }
 }
 
@@ -212,22 +238,32 @@ static int ew_check(const char* name, const void* a, int lda, const void* b, int
   return MUD_OK;
 }
 
+static dim3 ew_grid(int64_t hw, int C4, int B) {
+  int64_t blocks = mud_cdiv(hw * C4, 256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  // grid.x * 256 must be >= C4 so that the loop stride (a multiple of C4) is positive
+  while (blocks * 256 < C4) ++blocks;
+  return dim3((unsigned)blocks, B);
+}
+
 extern "C" int mud_mul(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t npix, int C, void* stream) {
   if (int e = ew_check("mud_mul", a, lda, b, ldb, out, ldo, C)) return e;
   if (npix == 0) return MUD_OK;
-  hipLaunchKernelGGL((k_ew3<0>), dim3(mud_grid_1d(npix * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
-                     (const float*)nullptr, 0, out, ldo, npix, C / 4);
+  hipLaunchKernelGGL((k_ew3<0>), ew_grid(npix, C / 4, 1), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     (const float*)nullptr, 0, out, ldo, npix, C / 4, (double*)nullptr, 0);
   MUD_CHECK_LAUNCH("mud_mul");
   return MUD_OK;
 }
 
 extern "C" int mud_gate_mix(const float* g, int ldg, const float* att, int lda, const float* other, int ldb, float* out,
-                            int ldo, int64_t npix, int C, void* stream) {
+                            int ldo, int B, int64_t hw, int C, double* stats, int stats_ld, void* stream) {
   if (int e = ew_check("mud_gate_mix", g, ldg, att, lda, out, ldo, C)) return e;
   MUD_REQUIRE(other && ldb % 4 == 0 && mud_aligned16(other), "mud_gate_mix: bad `other` view");
-  if (npix == 0) return MUD_OK;
-  hipLaunchKernelGGL((k_ew3<1>), dim3(mud_grid_1d(npix * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, att, lda,
-                     other, ldb, out, ldo, npix, C / 4);
+  MUD_REQUIRE(B >= 0 && B <= 65535 && hw >= 0 && (!stats || stats_ld >= C), "mud_gate_mix: bad sizes");
+  if (B == 0 || hw == 0) return MUD_OK;
+  hipLaunchKernelGGL((k_ew3<1>), ew_grid(hw, C / 4, B), dim3(256), stats ? 2 * C * sizeof(float) : 0, (hipStream_t)stream, g, ldg, att,
+                     lda, other, ldb, out, ldo, hw, C / 4, stats, stats_ld);
   MUD_CHECK_LAUNCH("mud_gate_mix");
   return MUD_OK;
 }

@@ -151,6 +151,43 @@ extern "C" int mud_gn_scale_shift(const float* x, int B, int64_t HW, int C, int 
   return MUD_OK;
 }
 
+__global__ __launch_bounds__(256) void k_gn_from_sums(const double* __restrict__ sums, int sums_ld, int C, int G, double count, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int64_t g_bstride,
+                                                      float* __restrict__ scale, float* __restrict__ shift, int ld_ss) {
+  const int b = blockIdx.x, cpg = C / G;
+  // one thread per group (G <= 32 in this model family; loop for generality)
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double s = 0.0, q = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      s += sums[((int64_t)b * sums_ld + c) * 2];
+      q += sums[((int64_t)b * sums_ld + c) * 2 + 1];
+    }
+    const double n = count * cpg, mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const float ga = gamma ? gamma[(int64_t)b * g_bstride + c] : 1.0f;
+      const float be = beta ? beta[(int64_t)b * g_bstride + c] : 0.0f;
+      const float sc = ga * rstd;
+      scale[(int64_t)b * ld_ss + c] = sc;
+      shift[(int64_t)b * ld_ss + c] = be - meanf * sc;
+    }
+  }
+}
+
+extern "C" int mud_gn_scale_shift_from_sums(const double* sums, int sums_ld, int B, int C, int G, double count, float eps,
+                                            const float* gamma, const float* beta, int64_t g_bstride, float* scale, float* shift,
+                                            int ld_ss, void* stream) {
+  MUD_REQUIRE(sums && scale && shift, "mud_gn_scale_shift_from_sums: null pointer");
+  MUD_REQUIRE(B >= 0 && C > 0 && G > 0 && C % G == 0 && sums_ld >= C && ld_ss >= C && count > 0, "mud_gn_scale_shift_from_sums: bad sizes");
+  if (B == 0) return MUD_OK;
+  hipLaunchKernelGGL(k_gn_from_sums, dim3(B), dim3(G <= 64 ? 64 : 256), 0, (hipStream_t)stream, sums, sums_ld, C, G, count, eps, gamma, beta,
+                     g_bstride, scale, shift, ld_ss);
+  MUD_CHECK_LAUNCH("mud_gn_scale_shift_from_sums");
+  return MUD_OK;
+}
+
 extern "C" int mud_channel_mean(const float* x, int B, int64_t HW, int C, int ld, float* out, int ldo, void* ws, void* stream) {
   if (int e = gn_common_checks("mud_channel_mean", x, B, HW, C, ld, ws)) return e;
   MUD_REQUIRE(out && ldo >= C, "mud_channel_mean: bad output");

@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ('res', C.c_void_p), ('ldr', C.c_int),
         ('out_scale', C.c_float), ('act', C.c_int),
         ('out', C.c_void_p), ('Cout', C.c_int), ('ldo', C.c_int),
+        ('stats', C.c_void_p), ('stats_ld', C.c_int),
     ]
 
 
@@ -50,6 +51,7 @@ _SIGNATURES = {
     'mud_dense': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mud_gn_ws_bytes': (_L, [_I, _L, _I, _I]),
     'mud_gn_scale_shift': (_I, [_P, _I, _L, _I, _I, _I, _F, _P, _P, _L, _P, _P, _I, _P, _P, _P]),
+    'mud_gn_scale_shift_from_sums': (_I, [_P, _I, _I, _I, _I, C.c_double, _F, _P, _P, _L, _P, _P, _I, _P]),
     'mud_channel_mean': (_I, [_P, _I, _L, _I, _I, _P, _I, _P, _P]),
     'mud_conv2d_direct': (_I, [C.POINTER(ConvArgs), _P]),
     'mud_packed_weight_bytes': (_L, [_I, _I, _I]),
@@ -59,7 +61,7 @@ _SIGNATURES = {
     'mud_fir_nhwc': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
     'mud_softmax_rows': (_I, [_P, _L, _I, _I, _P]),
     'mud_mul': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
-    'mud_gate_mix': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P]),
+    'mud_gate_mix': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _L, _I, _P, _I, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -11,18 +11,46 @@ from . import (ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE, PRO_AFFINE
                MudiffHipError, check, load, ptr, require_gpu, stream_ptr)
 
 
-class View:
-    """NHWC fp32 view (ptr, B, H, W, C, ld) into a torch tensor that owns the memory."""
-    __slots__ = ('base', 'B', 'H', 'W', 'C', 'ld', 'c0')
+class StatsArena:
+    """Zeroed fp64 scratch for the per-(sample, channel) (sum, sumsq) accumulators that producers fill in
+    their epilogues for the next GroupNorm.  One memset per chunk instead of one per tensor."""
 
-    def __init__(self, base, B, H, W, C, ld=None, c0=0):
+    def __init__(self, device, chunk_doubles=1 << 18):
+        self.device, self.chunk = device, chunk_doubles
+        self.buf, self.used = None, 0
+
+    def take(self, B, C):
+        n = B * C * 2
+        if self.buf is None or self.used + n > self.buf.numel():
+            self.buf = torch.zeros(max(self.chunk, n), device=self.device, dtype=torch.float64)
+            self.used = 0
+        t = self.buf[self.used:self.used + n].view(B, C, 2)
+        self.used += n
+        return t
+
+
+class View:
+    """NHWC fp32 view (ptr, B, H, W, C, ld) into a torch tensor that owns the memory.  `stats`, when
+    present, is a [B, ld, 2] fp64 tensor aligned with the buffer's channel axis that producers of this
+    view accumulate per-channel (sum, sum of squares) into (see mud_conv_args.stats)."""
+    __slots__ = ('base', 'B', 'H', 'W', 'C', 'ld', 'c0', 'stats')
+
+    def __init__(self, base, B, H, W, C, ld=None, c0=0, stats=None):
         self.base, self.B, self.H, self.W, self.C = base, B, H, W, C
         self.ld = C if ld is None else ld
         self.c0 = c0
+        self.stats = stats
 
     @staticmethod
-    def empty(B, H, W, C, device):
-        return View(torch.empty(B, H, W, C, device=device, dtype=torch.float32), B, H, W, C)
+    def empty(B, H, W, C, device, arena=None):
+        v = View(torch.empty(B, H, W, C, device=device, dtype=torch.float32), B, H, W, C)
+        if arena is not None:
+            v.stats = arena.take(B, C)
+        return v
+
+    @property
+    def stats_ptr(self):
+        return None if self.stats is None else C.c_void_p(self.stats.data_ptr() + 16 * self.c0)
 
     @staticmethod
     def from_nchw(x):
@@ -45,7 +73,7 @@ class View:
 
     def slice(self, c0, C_):
         assert 0 <= c0 and c0 + C_ <= self.C
-        return View(self.base, self.B, self.H, self.W, C_, self.ld, self.c0 + c0)
+        return View(self.base, self.B, self.H, self.W, C_, self.ld, self.c0 + c0, self.stats)
 
     @property
     def ptr(self):
@@ -174,7 +202,6 @@ def gn_scale_shift(x: View, G, gamma=None, beta=None, eps=1e-6):
     """-> (scale [B,C], shift [B,C]).  gamma/beta: None, [C] or [B,C] (row-strided views allowed)."""
     lib = load()
     HW = x.H * x.W
-    ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, G))
     ss = torch.empty(2, x.B, x.C, device=x.device, dtype=torch.float32)
     bstride = 0
     if gamma is not None:
@@ -182,6 +209,11 @@ def gn_scale_shift(x: View, G, gamma=None, beta=None, eps=1e-6):
         if gamma.dim() == 2:
             assert gamma.shape[0] == x.B and gamma.stride(0) == beta.stride(0)
             bstride = gamma.stride(0)
+    if x.stats is not None:      # the producers already accumulated (sum, sumsq): no pass over the tensor
+        _launch('gn_from_sums', lib.mud_gn_scale_shift_from_sums, x.stats_ptr, x.stats.shape[1], x.B, x.C, G, float(HW), eps, ptr(gamma),
+                ptr(beta), bstride, ptr(ss[0]), ptr(ss[1]), x.C, stream_ptr())
+        return ss[0], ss[1]
+    ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, G))
     _launch('gn_scale_shift', lib.mud_gn_scale_shift, x.ptr, x.B, HW, x.C, x.ld, G, eps, ptr(gamma), ptr(beta), bstride, ptr(ss[0]),
             ptr(ss[1]), x.C, None, ptr(ws), stream_ptr(), nbytes=4.0 * x.npix * x.C)
     return ss[0], ss[1]
@@ -227,14 +259,14 @@ def direct_weight(w_oihw):
 
 
 def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None, bias2=None, res: View = None,
-         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0):
+         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None):
     """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode)."""
     lib = load()
     pad = ks // 2 if pad is None else pad
     Ho = (x.H + 2 * pad - ks) // stride + 1
     Wo = (x.W + 2 * pad - ks) // stride + 1
     if out is None:
-        out = View.empty(x.B, Ho, Wo, Cout, x.device)
+        out = View.empty(x.B, Ho, Wo, Cout, x.device, arena)
     assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, Cout), ((out.B, out.H, out.W, out.C), (x.B, Ho, Wo, Cout))
     a = ConvArgs()
     a.x, a.B, a.H, a.W, a.Cin, a.ldx = x.ptr, x.B, x.H, x.W, x.C, x.ld
@@ -257,6 +289,8 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
         a.res, a.ldr = res.ptr, res.ld
     a.out_scale, a.act = out_scale, act
     a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
+    if out.stats is not None:
+        a.stats, a.stats_ld = out.stats_ptr, out.stats.shape[1]
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks
@@ -315,7 +349,8 @@ def mul(a: View, b: View, out: View = None):
 
 
 def gate_mix(g: View, att: View, other: View, out: View):
-    _launch('gate_mix', load().mud_gate_mix, g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.npix, g.C, stream_ptr())
+    _launch('gate_mix', load().mud_gate_mix, g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.B, g.H * g.W, g.C,
+            out.stats_ptr, out.stats.shape[1] if out.stats is not None else 0, stream_ptr())
     return out
 
 

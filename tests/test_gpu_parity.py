@@ -150,6 +150,32 @@ def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
     assert maxdiff(out, ref) < 3e-5
 
 
+@pytest.mark.parametrize('mfma,Cin,Cout,H,W', [(True, 32, 96, 20, 37), (True, 64, 64, 64, 64), (False, 1, 64, 31, 17), (False, 8, 24, 16, 16)])
+def test_epilogue_statistics_equal_two_pass_groupnorm(mfma, Cin, Cout, H, W):
+    """A producer's epilogue accumulates per-channel (sum, sumsq) of what it stores; GroupNorm from those
+    sums must equal GroupNorm from a pass over the tensor (and torch)."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=gen)
+    arena = ops.StatsArena(torch.device(DEV))
+    wide = ops.View.empty(B, H, W, Cout + 16, DEV, arena)             # the output is a channel slice of a wider buffer
+    out = wide.slice(8, Cout)
+    wp = ops.pack_conv_weight(g(w)) if mfma else ops.direct_weight(g(w))
+    ops.conv(ops.View.from_nchw(g(x)), wp, 3, Cout, mfma=mfma, bias=g(b), out=out)
+    G = min(Cout // 4, 32)
+    gamma, beta = g(torch.randn(B, Cout, generator=gen)), g(torch.randn(B, Cout, generator=gen))
+    sc1, sh1 = ops.gn_scale_shift(out, G, gamma, beta)                 # from the epilogue sums
+    plain = ops.View(wide.base, B, H, W, Cout, wide.ld, 8)             # same memory, no stats -> two-pass kernel
+    sc2, sh2 = ops.gn_scale_shift(plain, G, gamma, beta)
+    assert maxdiff(sc1, sc2) < 2e-6 and maxdiff(sh1, sh2) < 2e-6
+    y = out.to_nchw().cpu()
+    ref = gamma.cpu()[:, :, None, None] * F.group_norm(y, G, eps=1e-6) + beta.cpu()[:, :, None, None]
+    assert maxdiff(y * sc1.cpu()[:, :, None, None] + sh1.cpu()[:, :, None, None], ref) < 2e-5
+
+
 def test_fir_against_reference_golden():
     ops, S, L, UD, *_ = _imports()
     from utils.op import upfirdn2d
@@ -181,8 +207,17 @@ def test_softmax_and_gates():
     a, b, c = (torch.randn(2, 16, 6, 5, generator=gen) for _ in range(3))
     va, vb, vc = (ops.View.from_nchw(g(t)) for t in (a, b, c))
     assert maxdiff(ops.mul(va, vb).to_nchw(), a * b) < 1e-7
-    out = ops.View.empty(2, 6, 5, 16, DEV)
-    assert maxdiff(ops.gate_mix(va, vb, vc, out).to_nchw(), a * b + (1 - a) * c) < 1e-6
+    arena = ops.StatsArena(torch.device(DEV))
+    out = ops.View.empty(2, 6, 5, 16, DEV, arena)
+    ref = a * b + (1 - a) * c
+    assert maxdiff(ops.gate_mix(va, vb, vc, out).to_nchw(), ref) < 1e-6
+    assert maxdiff(out.stats[..., 0], ref.sum(dim=(2, 3))) < 1e-4 and maxdiff(out.stats[..., 1], (ref * ref).sum(dim=(2, 3))) < 1e-4
+    for C in (48, 192):          # channel counts that do not divide the block size
+        a, b, c = (torch.randn(2, C, 9, 7, generator=gen) for _ in range(3))
+        out = ops.View.empty(2, 9, 7, C, DEV, arena)
+        ref = a * b + (1 - a) * c
+        assert maxdiff(ops.gate_mix(*(ops.View.from_nchw(g(t)) for t in (a, b, c)), out).to_nchw(), ref) < 1e-6
+        assert maxdiff(out.stats[..., 0], ref.sum(dim=(2, 3))) < 1e-4
 
 
 def test_blocks_against_reference_golden():
@@ -286,11 +321,13 @@ def test_graph_sampler_matches_eager_and_batches():
     eager = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], 4, x_init, None, cfg, zs=zs, noises=noises)
     gs = S.GraphSampler(coef, g1, g2, cfg, B, 32, 32, DEV)
     graphed = gs.sample(conds[0], conds[1], conds[2], x_init, 4, zs=zs, noises=noises)
-    assert torch.equal(eager, graphed)
+    # fp64 atomics in the GroupNorm statistics make the last bit of a scale order-dependent; the bf16 hi/lo split
+    # turns such a 1-ulp input change into a ~2^-17 local change, so two runs agree to ~1e-5, not bitwise
+    assert maxdiff(eager, graphed) < 1e-4
     # slices are independent: sample 1 alone == sample 1 inside the batch (data-parallel sharding is exact)
     solo = S.sample_from_model(coef, g1, conds[0][1:2], g2, conds[1][1:2], conds[2][1:2], 4, x_init[1:2], None, cfg,
                                zs=[z[1:2] for z in zs], noises=[n[1:2] for n in noises])
-    assert maxdiff(solo, eager[1:2]) < 1e-5
+    assert maxdiff(solo, eager[1:2]) < 1e-4    # same arithmetic per slice; only the grouping of the statistics partial sums differs
     # oracle on the same batch
     sd1, sd2 = O.make_state_dict(cfg, 'g1', 1234), O.make_state_dict(cfg, 'g2', 1234)
     ref = O.sample_from_model(O.PosteriorCoefficients(cfg), sd1, sd2, cfg, *[c.cpu() for c in conds], x_init.cpu(),
