@@ -52,6 +52,8 @@ struct CmGeo {
 };
 
 
+__device__ __forceinline__ bool mud_dev_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
 __device__ __forceinline__ float cm_fast_silu(float v) {
   // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): the result is rounded to bf16 hi+lo (2^-17) anyway
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
@@ -214,51 +216,106 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   }
 
   // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]
-  float* st_lds = (float*)smem;                 // [wave][64 ch][2] per-channel (sum, sumsq) of this block's outputs
+  // Fast path: every 32x32 accumulator tile is transposed through a wave-private LDS patch so that a lane owns
+  // 4 consecutive channels of one pixel: residual loads and output stores are 16 B per lane (4 instructions per
+  // tile instead of 16 scalar ones); the same pass folds the per-channel GroupNorm statistics.
+  constexpr int EP_LD = 36;                                     // floats per staged pixel row (16-B aligned, bank-spread)
+  float* ep = (float*)smem + wave * (32 * EP_LD);               // the A buffers are dead after the last barrier
+  float* st_lds = (float*)smem + 4 * (32 * EP_LD);              // [wave][64 ch][2]
+  const bool vec = ((a.Cout | a.ldo | (a.res ? a.ldr : 0)) & 3) == 0 && mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res));
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int co = nt * CM_BN + n * 32 + r;
     const bool cok = co < a.Cout;
     float badd = (a.bias && cok) ? a.bias[co] : 0.f;
     if (a.bias2 && cok) badd += a.bias2[(int64_t)b * a.bias2_ld + co];
-    float ssum = 0.f, ssq = 0.f;
+    if (vec) {
+      const int col = (lane & 7) * 4, co4 = nt * CM_BN + n * 32 + col;   // this lane's 4 channels in the read-back phase
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int prow = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-        int64_t opix;
-        bool valid;
-        if (KS == 3) {
-          const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
-          valid = gy < a.H && gx < a.W;
-          opix = ((int64_t)b * a.H + gy) * a.W + gx;
-        } else {
-          const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
-          valid = fp < HW;
-          opix = (int64_t)b * HW + fp;
-        }
-        if (valid && cok) {
-          float v = acc[m][n][reg] + badd;
-          if (a.res) v += a.res[opix * a.ldr + co];
-          v = mud_act(v * a.out_scale, a.act);
-          a.out[opix * a.ldo + co] = v;
-          ssum += v;
-          ssq += v * v;
+        for (int reg = 0; reg < 16; ++reg) ep[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * EP_LD + r] = acc[m][n][reg] + badd;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int prow = pass * 8 + (lane >> 3);
+          int64_t opix;
+          bool valid;
+          if (KS == 3) {
+            const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
+            valid = gy < a.H && gx < a.W;
+            opix = ((int64_t)b * a.H + gy) * a.W + gx;
+          } else {
+            const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
+            valid = fp < HW;
+            opix = (int64_t)b * HW + fp;
+          }
+          f32x4 v = *(const f32x4*)(ep + prow * EP_LD + col);
+          if (valid && co4 < a.Cout) {
+            if (a.res) v += *(const f32x4*)(a.res + opix * a.ldr + co4);
+            v *= a.out_scale;
+            if (a.act != MUD_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
+            }
+            *(f32x4*)(a.out + opix * a.ldo + co4) = v;
+            s4 += v;
+            q4 += v * v;
+          }
         }
       }
-    }
-    if (a.stats) {                              // wave-uniform
-      ssum += __shfl_xor(ssum, 32, 64);         // the two half-waves hold the same channel
-      ssq += __shfl_xor(ssq, 32, 64);
-      if (hh == 0) {
-        st_lds[(wave * 64 + n * 32 + r) * 2] = ssum;
-        st_lds[(wave * 64 + n * 32 + r) * 2 + 1] = ssq;
+      if (a.stats) {                            // lanes with equal (lane & 7) hold the same 4 channels
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float ss = s4[e], qq = q4[e];
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) { ss += __shfl_xor(ss, o, 64); qq += __shfl_xor(qq, o, 64); }
+          if (lane < 8) {
+            st_lds[(wave * 64 + n * 32 + col + e) * 2] = ss;
+            st_lds[(wave * 64 + n * 32 + col + e) * 2 + 1] = qq;
+          }
+        }
+      }
+    } else {
+      float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int prow = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+          int64_t opix;
+          bool valid;
+          if (KS == 3) {
+            const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
+            valid = gy < a.H && gx < a.W;
+            opix = ((int64_t)b * a.H + gy) * a.W + gx;
+          } else {
+            const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
+            valid = fp < HW;
+            opix = (int64_t)b * HW + fp;
+          }
+          if (valid && cok) {
+            float v = acc[m][n][reg] + badd;
+            if (a.res) v += a.res[opix * a.ldr + co];
+            v = mud_act(v * a.out_scale, a.act);
+            a.out[opix * a.ldo + co] = v;
+            ssum += v;
+            ssq += v * v;
+          }
+        }
+      }
+      if (a.stats) {                            // wave-uniform
+        ssum += __shfl_xor(ssum, 32, 64);       // the two half-waves hold the same channel
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (hh == 0) {
+          st_lds[(wave * 64 + n * 32 + r) * 2] = ssum;
+          st_lds[(wave * 64 + n * 32 + r) * 2 + 1] = ssq;
+        }
       }
     }
   }
   if (a.stats) {
-    __syncthreads();                            // (the main loop ended with a barrier: the A buffers are dead)
+    __syncthreads();
     if (tid < 128) {
       const int ch = tid >> 1, k = tid & 1, co = nt * CM_BN + ch;
       if (co < a.Cout) {
