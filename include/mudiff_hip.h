@@ -98,6 +98,10 @@ typedef struct mud_conv_args {
   const float* res; int ldr;                     /* residual view [B,Ho,Wo,Cout] or NULL             */
   float out_scale; int act;                      /* out = act((acc+bias+bias2+res)*out_scale)        */
   float* out; int Cout, ldo;                     /* output view [B,Ho,Wo,Cout]                       */
+  int sub2;                                      /* mud_conv2d_mfma, ks 3 only: compute the stride-1  */
+                                                 /* pad-1 result and keep only odd (y,x) positions as */
+                                                 /* out[(y-1)/2,(x-1)/2] == stride-2 pad-0 convolution */
+                                                 /* of the input (the FIR'd pyramid, odd H and W)      */
   double* stats; int stats_ld;                   /* optional: per-(b, channel) running (sum, sum of   */
                                                  /* squares) of the STORED outputs, stats[(b*stats_ld */
                                                  /* + co)*2 + {0,1}] += ... (fp64 atomics); lets the   */

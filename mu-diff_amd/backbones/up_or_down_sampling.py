@@ -92,10 +92,11 @@ class Conv2d(nn.Module):
         self.up, self.down, self.resample_kernel, self.kernel, self.use_bias = up, down, resample_kernel, kernel, use_bias
         self._prep = None
 
-    def _weights(self):
-        key = (self.weight._version, self.weight.data_ptr())
+    def _weights(self, mfma=False):
+        key = (self.weight._version, self.weight.data_ptr(), mfma)
         if self._prep is None or self._prep[0] != key:
-            self._prep = (key, ops.direct_weight(self.weight))
+            with torch.no_grad():
+                self._prep = (key, ops.pack_conv_weight(self.weight) if mfma else ops.direct_weight(self.weight))
         return self._prep[1]
 
     def run(self, x: View, res: View = None, out_scale=1.0, out: View = None):
@@ -106,6 +107,12 @@ class Conv2d(nn.Module):
         if not self.down:
             return ops.conv(x, self._weights(), self.kernel, self.weight.shape[0], mfma=False, bias=bias, res=res, out_scale=out_scale, out=out)
         kk, up, down, pad = fir_params('conv_down', self.resample_kernel, conv_k=self.kernel)
+        if x.C % 4 == 0 and x.C >= 8 and self.kernel == 3 and x.H % 2 == 0 and x.W % 2 == 0:
+            # matrix-core path: the stride-2 pad-0 conv of the FIR'd (H+1)x(W+1) image is the odd-position subset
+            # of the stride-1 pad-1 conv (4x the MFMA work, still ~5x faster than the direct kernel)
+            xf, _ = ops.fir_nhwc(x, kk, up, down, pad)
+            return ops.conv(xf, self._weights(mfma=True), 3, self.weight.shape[0], mfma=True, bias=bias, res=res, out_scale=out_scale,
+                            out=out, sub2=True)
         if x.C % 4 == 0:
             xf, _ = ops.fir_nhwc(x, kk, up, down, pad)
         else:   # single-channel image pyramid: NHWC == planes

@@ -98,6 +98,75 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
   }
 }
 
+// Cin == 1, 3x3, stride 1, pad 1 (the ConvFeatBlock / ConvBlock head convolutions): a 256 B/pixel store
+// stream.  A thread owns 4 output channels, keeps their 9x4 weights + bias in registers and walks PIX_PER
+// pixels of a row; 16 lanes cover the 64 channels of a pixel, so every wave store is 1 KiB contiguous.
+#define HEAD_PIX 8
+__global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_groups) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* st_lds = (float*)smem_raw;
+  const int b = blockIdx.y;
+  if (a.stats) {
+    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) st_lds[i] = 0.f;
+    __syncthreads();
+  }
+  const int cg = threadIdx.x % co_groups, co = cg * 4;
+  const int ppb = 256 / co_groups;                      // pixels handled concurrently by the block
+  const int lp = threadIdx.x / co_groups;
+  f32x4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)((const float*)a.w + (int64_t)t * a.Cout + co);
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias = *(const f32x4*)(a.bias + co);
+  if (a.bias2) bias += *(const f32x4*)(a.bias2 + (int64_t)b * a.bias2_ld + co);
+  const float* xb = a.x + (int64_t)b * a.H * a.W * a.ldx;
+  const int64_t HW = (int64_t)a.H * a.W;
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+  const bool active = lp < ppb;
+  for (int64_t p0 = ((int64_t)blockIdx.x * HEAD_PIX) * ppb; p0 < HW && active; p0 += (int64_t)gridDim.x * HEAD_PIX * ppb) {
+#pragma unroll
+    for (int k = 0; k < HEAD_PIX; ++k) {
+      const int64_t p = p0 + (int64_t)k * ppb + lp;
+      if (p >= HW) break;
+      const int y = (int)(p / a.W), x = (int)(p - (int64_t)y * a.W);
+      f32x4 acc = bias;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int iy = y + dy - 1;
+        if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int ix = x + dx - 1;
+          if (ix < 0 || ix >= a.W) continue;
+          acc += xb[((int64_t)iy * a.W + ix) * a.ldx] * w[dy * 3 + dx];
+        }
+      }
+      const int64_t opix = (int64_t)b * HW + p;
+      if (a.res) acc += *(const f32x4*)(a.res + opix * a.ldr + co);
+      acc *= a.out_scale;
+      if (a.act != MUD_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = mud_act(acc[e], a.act);
+      }
+      *(f32x4*)(a.out + opix * a.ldo + co) = acc;
+      s4 += acc;
+      q4 += acc * acc;
+    }
+  }
+  if (a.stats) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&st_lds[(co + e) * 2], s4[e]);
+        atomicAdd(&st_lds[(co + e) * 2 + 1], q4[e]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256)
+      atomicAdd(a.stats + ((int64_t)b * a.stats_ld + (i >> 1)) * 2 + (i & 1), (double)st_lds[i]);
+  }
+}
+
 extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(ap, "mud_conv2d_direct: null args");
   const mud_conv_args a = *ap;
@@ -113,6 +182,17 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   const bool vo4 = a.Cout % 4 == 0 && a.ldo % 4 == 0 && mud_aligned16(a.out) && mud_aligned16(a.w) && (a.w_bstride % 16 == 0);
   const bool vi4 = a.Cin % 4 == 0 && a.ldx % 4 == 0 && mud_aligned16(a.x);
   const int co_groups = vo4 ? a.Cout / 4 : a.Cout;
+  if (a.Cin == 1 && a.ks == 3 && a.stride == 1 && a.pad == 1 && vo4 && co_groups <= 256 && a.pro_mode == MUD_PRO_NONE && a.w_bstride == 0 &&
+      (!a.res || (a.ldr % 4 == 0 && mud_aligned16(a.res))) && (!a.bias || mud_aligned16(a.bias)) &&
+      (!a.bias2 || (a.bias2_ld % 4 == 0 && mud_aligned16(a.bias2)))) {
+    MUD_REQUIRE(a.B <= 65535 && (!a.stats || a.stats_ld >= a.Cout), "mud_conv2d_direct: bad batch / stats view");
+    const int ppb = 256 / co_groups;
+    int64_t blocks = mud_cdiv((int64_t)Ho * Wo, (int64_t)ppb * HEAD_PIX);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_conv_head3x3, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups);
+    MUD_CHECK_LAUNCH("mud_conv2d_direct(head)");
+    return MUD_OK;
+  }
   const int64_t total = (int64_t)Ho * Wo * co_groups;
   int64_t blocks = mud_cdiv(total, 256 * (a.stats ? 8 : 1));   // several outputs per thread when the block folds statistics
   if (blocks > 256 * 32) blocks = 256 * 32;

@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
             const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
             valid = gy < a.H && gx < a.W;
             opix = ((int64_t)b * a.H + gy) * a.W + gx;
+            if (a.sub2) {
+              valid = valid && (gy & 1) && (gx & 1);
+              opix = ((int64_t)b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1);
+            }
           } else {
             const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
             valid = fp < HW;
@@ -289,6 +293,10 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
             const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
             valid = gy < a.H && gx < a.W;
             opix = ((int64_t)b * a.H + gy) * a.W + gx;
+            if (a.sub2) {
+              valid = valid && (gy & 1) && (gx & 1);
+              opix = ((int64_t)b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1);
+            }
           } else {
             const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
             valid = fp < HW;
@@ -428,6 +436,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(mud_aligned16(a.w) && a.w_bstride % 16 == 0, "mud_conv2d_mfma: packed weights must be 16-byte aligned");
   MUD_REQUIRE(a.ldo >= a.Cout && (!a.res || a.ldr >= a.Cout), "mud_conv2d_mfma: bad output/residual view");
   MUD_REQUIRE(!a.stats || a.stats_ld >= a.Cout, "mud_conv2d_mfma: bad stats view");
+  MUD_REQUIRE(!a.sub2 || (a.ks == 3 && (a.H & 1) && (a.W & 1)), "mud_conv2d_mfma: sub2 needs ks == 3 and odd H, W");
   if (a.pro_mode != MUD_PRO_NONE) {
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),
                 "mud_conv2d_mfma: prologue arrays missing or misaligned");

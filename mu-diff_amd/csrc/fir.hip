@@ -65,7 +65,9 @@ extern "C" int mud_upfirdn2d(const float* in, int64_t planes, int H, int W, cons
   return MUD_OK;
 }
 
-template <bool WITH_H, bool WITH_X>
+// UP/DOWN = 0: runtime up/down and kernel size (generic).  UP/DOWN > 0: compile-time factors with a 4x4 kernel:
+// the tap loops are unrolled and, for UP == 2, only the 2x2 polyphase taps that land on real samples are visited.
+template <bool WITH_H, bool WITH_X, int UP, int DOWN>
 __global__ __launch_bounds__(256) void k_fir_nhwc(const float* __restrict__ x, int B, int H, int W, int C4, int ldx, FirKernel fk,
                                                   int kh, int kw, int up, int down, int pad0, int Ho, int Wo,
                                                   const float* __restrict__ psc, const float* __restrict__ psh, int pro_ld,
@@ -85,23 +87,34 @@ __global__ __launch_bounds__(256) void k_fir_nhwc(const float* __restrict__ x, i
       sh = *(const f32x4*)(psh + (int64_t)b * pro_ld + c);
     }
     f32x4 ah = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < kh; ++m) {
-      const int Y = oy * down + m - pad0;
-      if (Y < 0 || Y % up) continue;
-      const int iy = Y / up;
+    constexpr bool SPEC = UP > 0;
+    const int upv = SPEC ? UP : up, downv = SPEC ? DOWN : down, khv = SPEC ? 4 : kh, kwv = SPEC ? 4 : kw;
+    // first tap whose (o*down + m - pad0) is a multiple of `up`, then every up-th tap
+    const int my0 = SPEC ? (((pad0 - oy * downv) % upv) + upv) % upv : 0;
+    const int mx0 = SPEC ? (((pad0 - ox * downv) % upv) + upv) % upv : 0;
+#pragma unroll
+    for (int mi = 0; mi < (SPEC ? 4 / UP : 64); ++mi) {
+      const int m = SPEC ? my0 + mi * upv : mi;
+      if (!SPEC && m >= khv) break;
+      const int Y = oy * downv + m - pad0;
+      if (Y < 0 || (!SPEC && Y % upv)) continue;
+      const int iy = Y / upv;
       if (iy >= H) continue;
-      for (int n = 0; n < kw; ++n) {
-        const int X = ox * down + n - pad0;
-        if (X < 0 || X % up) continue;
-        const int ix = X / up;
+#pragma unroll
+      for (int ni = 0; ni < (SPEC ? 4 / UP : 64); ++ni) {
+        const int n = SPEC ? mx0 + ni * upv : ni;
+        if (!SPEC && n >= kwv) break;
+        const int X = ox * downv + n - pad0;
+        if (X < 0 || (!SPEC && X % upv)) continue;
+        const int ix = X / upv;
         if (ix >= W) continue;
-        const float kv = fk.k[(kh - 1 - m) * kw + (kw - 1 - n)];
+        const float kv = fk.k[(khv - 1 - m) * kwv + (kwv - 1 - n)];
         const f32x4 v = *(const f32x4*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + c);
         if (WITH_X) ax += kv * v;
         if (WITH_H) {
           f32x4 t;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = mud_prologue(v[j], sc[j], sh[j], pro_mode);
+          for (int j = 0; j < 4; ++j) t[j] = mud_prologue_fast(v[j], sc[j], sh[j], pro_mode);
           ah += kv * t;
         }
       }
@@ -130,10 +143,13 @@ extern "C" int mud_fir_nhwc(const float* x, int B, int H, int W, int C, int ldx,
   if (blocks > 256 * 32) blocks = 256 * 32;
   dim3 grid((int)blocks), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define FIR_LAUNCH(HH, XX) hipLaunchKernelGGL((k_fir_nhwc<HH, XX>), grid, block, 0, s, x, B, H, W, C / 4, ldx, fk, kh, kw, up, down, pad0, Ho, Wo, pro_scale, pro_shift, pro_ld, pro_mode, out_h, ldh, out_x, ldxo)
-  if (out_h && out_x) FIR_LAUNCH(true, true);
-  else if (out_h) FIR_LAUNCH(true, false);
-  else FIR_LAUNCH(false, true);
+#define FIR_LAUNCH(HH, XX, UU, DD) hipLaunchKernelGGL((k_fir_nhwc<HH, XX, UU, DD>), grid, block, 0, s, x, B, H, W, C / 4, ldx, fk, kh, kw, up, down, pad0, Ho, Wo, pro_scale, pro_shift, pro_ld, pro_mode, out_h, ldh, out_x, ldxo)
+#define FIR_PICK(UU, DD) do { if (out_h && out_x) FIR_LAUNCH(true, true, UU, DD); else if (out_h) FIR_LAUNCH(true, false, UU, DD); else FIR_LAUNCH(false, true, UU, DD); } while (0)
+  if (kh == 4 && kw == 4 && up == 2 && down == 1) FIR_PICK(2, 1);
+  else if (kh == 4 && kw == 4 && up == 1 && down == 2) FIR_PICK(1, 2);
+  else if (kh == 4 && kw == 4 && up == 1 && down == 1) FIR_PICK(1, 1);
+  else FIR_PICK(0, 0);
+#undef FIR_PICK
 #undef FIR_LAUNCH
   MUD_CHECK_LAUNCH("mud_fir_nhwc");
   return MUD_OK;

@@ -45,10 +45,21 @@ __device__ __forceinline__ float mud_act(float v, int act) {
   }
 }
 
+// v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp, ~3e-7 relative overall): used where the value
+// feeds a bf16 hi+lo split (2^-17) or a 16-tap filter, and a full-precision expf + divide would dominate
+__device__ __forceinline__ float mud_fast_silu(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
+
 __device__ __forceinline__ float mud_prologue(float v, float sc, float sh, int mode) {
   if (mode == MUD_PRO_NONE) return v;
   v = fmaf(v, sc, sh);
   return mode == MUD_PRO_AFFINE_SILU ? mud_silu(v) : v;
+}
+__device__ __forceinline__ float mud_prologue_fast(float v, float sc, float sh, int mode) {
+  if (mode == MUD_PRO_NONE) return v;
+  v = fmaf(v, sc, sh);
+  return mode == MUD_PRO_AFFINE_SILU ? mud_fast_silu(v) : v;
 }
 
 // 64-lane butterfly sums

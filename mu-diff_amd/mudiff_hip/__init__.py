@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ('res', C.c_void_p), ('ldr', C.c_int),
         ('out_scale', C.c_float), ('act', C.c_int),
         ('out', C.c_void_p), ('Cout', C.c_int), ('ldo', C.c_int),
+        ('sub2', C.c_int),
         ('stats', C.c_void_p), ('stats_ld', C.c_int),
     ]
 

@@ -259,12 +259,15 @@ def direct_weight(w_oihw):
 
 
 def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None, bias2=None, res: View = None,
-         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None):
+         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None, sub2=False):
     """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode)."""
     lib = load()
     pad = ks // 2 if pad is None else pad
     Ho = (x.H + 2 * pad - ks) // stride + 1
     Wo = (x.W + 2 * pad - ks) // stride + 1
+    if sub2:      # stride-2 pad-0 result obtained from the stride-1 pad-1 kernel by keeping odd positions
+        assert mfma and ks == 3 and stride == 1 and x.H % 2 == 1 and x.W % 2 == 1
+        Ho, Wo = x.H // 2, x.W // 2
     if out is None:
         out = View.empty(x.B, Ho, Wo, Cout, x.device, arena)
     assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, Cout), ((out.B, out.H, out.W, out.C), (x.B, Ho, Wo, Cout))
@@ -288,12 +291,13 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
         assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, Cout)
         a.res, a.ldr = res.ptr, res.ld
     a.out_scale, a.act = out_scale, act
+    a.sub2 = 1 if sub2 else 0
     a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
     if out.stats is not None:
         a.stats, a.stats_ld = out.stats_ptr, out.stats.shape[1]
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
-    flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks
+    flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks     # algorithmic (sub2 issues 4x this)
     nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * (2 if res is not None else 1)) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
     _launch(name, fn, C.byref(a), stream_ptr(), flops=flops, nbytes=nbytes)
     return out
