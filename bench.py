@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '8')), help='slices per GPU per step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '16')), help='slices per GPU per step')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')

@@ -99,10 +99,12 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
 }
 
 // Cin == 1, 3x3, stride 1, pad 1 (the ConvFeatBlock / ConvBlock head convolutions): a 256 B/pixel store
-// stream.  A thread owns 4 output channels, keeps their 9x4 weights + bias in registers and walks PIX_PER
-// pixels of a row; 16 lanes cover the 64 channels of a pixel, so every wave store is 1 KiB contiguous.
+// stream.  A thread owns 4 output channels (their 9x4 weights + bias live in registers) and a strip of
+// HEAD_PIX consecutive pixels of one row: the 3 x (HEAD_PIX+2) input window is loaded once, branch-free
+// (clamped address x 0/1 mask), and reused by the 9 taps.  co_groups lanes cover one pixel's channels, so
+// stores are 16 B per lane in runs of 4*co_groups*4 B (256 B for 64 channels).
 #define HEAD_PIX 8
-__global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_groups) {
+__global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_groups, int strips_per_row) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* st_lds = (float*)smem_raw;
   const int b = blockIdx.y;
@@ -111,37 +113,44 @@ __global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_gr
     __syncthreads();
   }
   const int cg = threadIdx.x % co_groups, co = cg * 4;
-  const int ppb = 256 / co_groups;                      // pixels handled concurrently by the block
-  const int lp = threadIdx.x / co_groups;
+  const int spb = 256 / co_groups;                      // strips handled concurrently by the block
+  const int ls = threadIdx.x / co_groups;
   f32x4 w[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)((const float*)a.w + (int64_t)t * a.Cout + co);
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias = *(const f32x4*)(a.bias + co);
   if (a.bias2) bias += *(const f32x4*)(a.bias2 + (int64_t)b * a.bias2_ld + co);
-  const float* xb = a.x + (int64_t)b * a.H * a.W * a.ldx;
   const int64_t HW = (int64_t)a.H * a.W;
+  const float* xb = a.x + (int64_t)b * HW * a.ldx;
   f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
-  const bool active = lp < ppb;
-  for (int64_t p0 = ((int64_t)blockIdx.x * HEAD_PIX) * ppb; p0 < HW && active; p0 += (int64_t)gridDim.x * HEAD_PIX * ppb) {
+  const int64_t nstrips = (int64_t)a.H * strips_per_row;
+  const bool active = ls < spb;
+  for (int64_t st = (int64_t)blockIdx.x * spb + ls; active && st < nstrips; st += (int64_t)gridDim.x * spb) {
+    const int y = (int)(st / strips_per_row), x0 = (int)(st - (int64_t)y * strips_per_row) * HEAD_PIX;
+    float win[3][HEAD_PIX + 2];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = y + dy - 1;
+      const bool yok = iy >= 0 && iy < a.H;
+      const int64_t rowoff = (int64_t)(yok ? iy : 0) * a.W;
+#pragma unroll
+      for (int j = 0; j < HEAD_PIX + 2; ++j) {
+        const int ix = x0 + j - 1;
+        const bool ok = yok && ix >= 0 && ix < a.W;
+        const float v = xb[(rowoff + (ok ? ix : 0)) * a.ldx];
+        win[dy][j] = ok ? v : 0.f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < HEAD_PIX; ++k) {
-      const int64_t p = p0 + (int64_t)k * ppb + lp;
-      if (p >= HW) break;
-      const int y = (int)(p / a.W), x = (int)(p - (int64_t)y * a.W);
+      if (x0 + k >= a.W) break;
       f32x4 acc = bias;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int iy = y + dy - 1;
-        if (iy < 0 || iy >= a.H) continue;
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int ix = x + dx - 1;
-          if (ix < 0 || ix >= a.W) continue;
-          acc += xb[((int64_t)iy * a.W + ix) * a.ldx] * w[dy * 3 + dx];
-        }
-      }
-      const int64_t opix = (int64_t)b * HW + p;
+        for (int dx = 0; dx < 3; ++dx) acc += win[dy][k + dx] * w[dy * 3 + dx];
+      const int64_t opix = (int64_t)b * HW + (int64_t)y * a.W + x0 + k;
       if (a.res) acc += *(const f32x4*)(a.res + opix * a.ldr + co);
       acc *= a.out_scale;
       if (a.act != MUD_ACT_NONE) {
@@ -186,10 +195,11 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
       (!a.res || (a.ldr % 4 == 0 && mud_aligned16(a.res))) && (!a.bias || mud_aligned16(a.bias)) &&
       (!a.bias2 || (a.bias2_ld % 4 == 0 && mud_aligned16(a.bias2)))) {
     MUD_REQUIRE(a.B <= 65535 && (!a.stats || a.stats_ld >= a.Cout), "mud_conv2d_direct: bad batch / stats view");
-    const int ppb = 256 / co_groups;
-    int64_t blocks = mud_cdiv((int64_t)Ho * Wo, (int64_t)ppb * HEAD_PIX);
+    const int spb = 256 / co_groups, strips_per_row = (int)mud_cdiv(Wo, HEAD_PIX);
+    int64_t blocks = mud_cdiv((int64_t)Ho * strips_per_row, spb);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_conv_head3x3, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups);
+    hipLaunchKernelGGL(k_conv_head3x3, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups,
+                       strips_per_row);
     MUD_CHECK_LAUNCH("mud_conv2d_direct(head)");
     return MUD_OK;
   }

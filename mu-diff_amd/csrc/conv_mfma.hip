@@ -19,14 +19,17 @@
 //     are fetched into registers before the MFMAs of chunk k and written to the other LDS buffer
 //     after them -> one barrier per chunk, global latency hidden under the matrix work.
 //   * B operand (weights): pre-split, pre-packed on the host side of the ABI into exactly the MFMA
-//     fragment order, so a wave's B fragment is ONE fully coalesced 1 KiB global load (L2-resident,
-//     shared by every workgroup) straight into registers - no LDS, no barrier; fetched two taps ahead.
+//     fragment order (16-B halves pre-swizzled).  Groups of 3 taps (12 KiB) are streamed global -> LDS by
+//     direct-to-LDS loads (global_load_lds_dwordx4: no VGPRs, each wave moves a quarter) into a 2-slot
+//     ring one group ahead of use and read back by all four waves with ds_read_b128: 4x less L1/TA
+//     traffic than per-wave fragment loads (measured: the TA path, not L2 capacity, was the limiter).
 //   * epilogue from the accumulators: + bias[co] + bias2[b,co] (time embedding) + residual, * scale,
 //     activation; each half-wave stores 32 consecutive channels (128 B) of one pixel.
 //   * workgroup ids are remapped so that the workgroups sharing an input tile (different output-channel
 //     tiles) and spatial neighbours run on the same XCD (shared L2).
 #include "mud_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define CM_BN 64
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
@@ -43,12 +46,17 @@ struct CmGeo {
   static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
   static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
   static constexpr int BUF = CH * PLANE;                // [k16 s]
-  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int LDS_BYTES = 2 * BUF + 2 * ((KS == 3) ? 3 : 2) * CM_BSTEP;   // A double buffer + B ring (2 groups)
   static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
   static constexpr int ITEMS = P * Q;
   static constexpr int NLOAD = (ITEMS + 255) / 256;
   static constexpr int STEPS = TAPS * CH;               // MFMA steps (tap, s) per chunk
-  static constexpr int RING = (KS == 3) ? 3 : 2;        // B fragment register ring (prefetch distance RING-1)
+  static constexpr int GS = (KS == 3) ? 3 : 2;          // steps per B group (one DMA batch, one barrier)
+  static constexpr int NG = STEPS / GS;                 // B groups per chunk
+  static constexpr int GB = GS * CM_BSTEP;              // bytes per B group (contiguous in the packed weights)
+  static constexpr int A_BYTES = 2 * BUF;
+  static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
+  static constexpr int LDS_TOTAL = A_BYTES + 2 * GB;
 };
 
 
@@ -87,7 +95,318 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
     flat0 = (int64_t)tile * G::P;
   }
   const float* xb = a.x + (int64_t)b * HW * a.ldx;
-  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * k16s * (G::TAPS * CM_BSTEP) + r * 32 + hh * 16;
+  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * k16s * (G::TAPS * CM_BSTEP);
+  const float* psc = a.pro_scale + (int64_t)b * a.pro_ld;
+  const float* psh = a.pro_shift + (int64_t)b * a.pro_ld;
+  const int nchunks = (k16s + G::CH - 1) / G::CH;
+
+  // ---- per-thread staging slots: pixel -> global element offset and LDS byte offset, fixed for all chunks.
+  // Everything below is branch-free: padding pixels load a clamped (valid) address and are zeroed by a 0/1
+  // mask; slots past the tile wrap around and redo another thread's item (identical value, same address).
+  const int q = tid % G::Q;                     // this thread's float4 (4 channels) inside a chunk
+  int goff[G::NLOAD], loff[G::NLOAD];
+  unsigned vmask = 0;                           // bit j: slot j is a real (non-padding) pixel
+#pragma unroll
+  for (int j = 0; j < G::NLOAD; ++j) {
+    const int item = (tid + j * 256) % G::ITEMS;   // 256 % Q == 0 and ITEMS % Q == 0: q is preserved
+    const int p = item / G::Q;
+    bool valid;
+    int64_t g;
+    if (KS == 3) {
+      const int py = p / G::PW, px = p - py * G::PW;
+      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+      valid = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      g = ((int64_t)gy * a.W + gx) * a.ldx;
+    } else {
+      const int64_t fp = flat0 + p;
+      valid = fp < HW;
+      g = fp * a.ldx;
+    }
+    goff[j] = valid ? (int)g : 0;
+    vmask |= (valid ? 1u : 0u) << j;
+    loff[j] = (q >> 2) * G::PLANE + p * CM_PIX + (q & 3) * 8;
+  }
+
+  f32x4 raw[G::NLOAD];
+  f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
+  auto fetch_a = [&](int chunk) {
+    int c = chunk * G::KCH + q * 4;
+    c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
+#pragma unroll
+    for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
+    if (PRO != MUD_PRO_NONE) {
+      psc_r = *(const f32x4*)(psc + c);
+      psh_r = *(const f32x4*)(psh + c);
+    }
+  };
+  auto store_a = [&](int chunk, char* buf) {
+    const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < G::NLOAD; ++j) {
+      f32x4 v = raw[j];
+      if (PRO != MUD_PRO_NONE) {
+        v = v * psc_r + psh_r;
+        if (PRO == MUD_PRO_AFFINE_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
+        }
+      }
+      const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
+      v = v * keep;
+      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+      const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+      *(bf16x4*)(buf + loff[j]) = hi;
+      *(bf16x4*)(buf + loff[j] + 32) = lo;
+    }
+  };
+
+  // ---- B operand: groups of GS steps are copied global -> LDS by direct-to-LDS loads (no VGPRs, 1 KiB per
+  // wave instruction, each wave moves a quarter of the group) into a 2-slot ring, one group ahead of its use.
+  // The packed layout already is the LDS image (16-B halves pre-swizzled for conflict-free ds_read_b128).
+  const int total_groups = (k16s * G::TAPS + G::GS - 1) / G::GS;
+  char* const bring = smem + G::B_OFF;
+  auto dma_b = [&](int gg) {                    // group gg -> ring slot gg & 1
+    if (gg >= total_groups) return;             // wave-uniform
+    const char* src = wb + (int64_t)gg * G::GB + lane * 16;
+    char* dst = bring + (gg & 1) * G::GB;
+#pragma unroll
+    for (int j = 0; j < G::GB / 4096; ++j) {
+      const int piece = wave + 4 * j;           // wave-uniform 1 KiB piece
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+  };
+  const int lane_b = r * 32 + ((hh ^ ((r >> 3) & 1)) << 4);   // this lane's 16 B inside a [32 co][32 B] fragment image
+
+  const int lane_a = ((KS == 3) ? (wave * MT * G::PW + r) : (wave * MT * 32 + r)) * CM_PIX + hh * 16;
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  // ---- prologue: chunk 0 into A buffer 0, B group 0 into ring slot 0
+  dma_b(0);
+  fetch_a(0);
+  store_a(0, smem);
+  __syncthreads();
+
+  for (int kc = 0; kc < nchunks; ++kc) {
+    char* cur = smem + (kc & 1) * G::BUF;
+    char* nxt = smem + ((kc + 1) & 1) * G::BUF;
+    const bool more = kc + 1 < nchunks;
+#pragma unroll
+    for (int g = 0; g < G::NG; ++g) {
+      const int gg = kc * G::NG + g;
+      dma_b(gg + 1);                            // next group's weights stream in under this group's MFMAs
+      if (g == 0 && more) fetch_a(kc + 1);
+      const char* bcur = bring + (gg & 1) * G::GB;
+#pragma unroll
+      for (int sg = 0; sg < G::GS; ++sg) {
+        const int st = g * G::GS + sg;          // step inside the chunk: KS=3: tap; KS=1: k16 half
+        const int s = (KS == 3) ? 0 : st;
+        const int tap = (KS == 3) ? st : 0;
+        const int dy = tap / KS, dx = tap % KS;
+        if (kc * G::CH + s < k16s) {
+          bf16x8 bh[2], bl[2];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            bh[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + n * 1024 + lane_b);
+            bl[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            // lane base (wave row, column r, k half hh) + compile-time (m, tap, s) offset
+            const int off = s * G::PLANE + ((KS == 3) ? ((m + dy) * G::PW + dx) : (m * 32)) * CM_PIX;
+            const bf16x8 ah = *(const bf16x8*)(cur + lane_a + off);
+            const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (g == (G::NG > 1 ? 1 : 0) && more) store_a(kc + 1, nxt);   // chunk k+1's LDS image, after its raw loads had a group to land
+      __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
+    }
+  }
+
+  // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]
+  // Fast path: every 32x32 accumulator tile is transposed through a wave-private LDS patch so that a lane owns
+  // 4 consecutive channels of one pixel: residual loads and output stores are 16 B per lane (4 instructions per
+  // tile instead of 16 scalar ones); the same pass folds the per-channel GroupNorm statistics.
+  constexpr int EP_LD = 36;                                     // floats per staged pixel row (16-B aligned, bank-spread)
+  float* ep = (float*)smem + wave * (32 * EP_LD);               // the A buffers are dead after the last barrier
+  float* st_lds = (float*)smem + 4 * (32 * EP_LD);              // [wave][64 ch][2]
+  const bool vec = ((a.Cout | a.ldo | (a.res ? a.ldr : 0)) & 3) == 0 && mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res));
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int co = nt * CM_BN + n * 32 + r;
+    const bool cok = co < a.Cout;
+    float badd = (a.bias && cok) ? a.bias[co] : 0.f;
+    if (a.bias2 && cok) badd += a.bias2[(int64_t)b * a.bias2_ld + co];
+    if (vec) {
+      const int col = (lane & 7) * 4, co4 = nt * CM_BN + n * 32 + col;   // this lane's 4 channels in the read-back phase
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) ep[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * EP_LD + r] = acc[m][n][reg] + badd;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int prow = pass * 8 + (lane >> 3);
+          int64_t opix;
+          bool valid;
+          if (KS == 3) {
+            const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
+            valid = gy < a.H && gx < a.W;
+            opix = ((int64_t)b * a.H + gy) * a.W + gx;
+            if (a.sub2) {
+              valid = valid && (gy & 1) && (gx & 1);
+              opix = ((int64_t)b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1);
+            }
+          } else {
+            const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
+            valid = fp < HW;
+            opix = (int64_t)b * HW + fp;
+          }
+          f32x4 v = *(const f32x4*)(ep + prow * EP_LD + col);
+          if (valid && co4 < a.Cout) {
+            if (a.res) v += *(const f32x4*)(a.res + opix * a.ldr + co4);
+            v *= a.out_scale;
+            if (a.act != MUD_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
+            }
+            *(f32x4*)(a.out + opix * a.ldo + co4) = v;
+            s4 += v;
+            q4 += v * v;
+          }
+        }
+      }
+      if (a.stats) {                            // lanes with equal (lane & 7) hold the same 4 channels
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float ss = s4[e], qq = q4[e];
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) { ss += __shfl_xor(ss, o, 64); qq += __shfl_xor(qq, o, 64); }
+          if (lane < 8) {
+            st_lds[(wave * 64 + n * 32 + col + e) * 2] = ss;
+            st_lds[(wave * 64 + n * 32 + col + e) * 2 + 1] = qq;
+          }
+        }
+      }
+    } else {
+      float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int prow = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+          int64_t opix;
+          bool valid;
+          if (KS == 3) {
+            const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
+            valid = gy < a.H && gx < a.W;
+            opix = ((int64_t)b * a.H + gy) * a.W + gx;
+            if (a.sub2) {
+              valid = valid && (gy & 1) && (gx & 1);
+              opix = ((int64_t)b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1);
+            }
+          } else {
+            const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
+            valid = fp < HW;
+            opix = (int64_t)b * HW + fp;
+          }
+          if (valid && cok) {
+            float v = acc[m][n][reg] + badd;
+            if (a.res) v += a.res[opix * a.ldr + co];
+            v = mud_act(v * a.out_scale, a.act);
+            a.out[opix * a.ldo + co] = v;
+            ssum += v;
+            ssq += v * v;
+          }
+        }
+      }
+      if (a.stats) {                            // wave-uniform
+        ssum += __shfl_xor(ssum, 32, 64);       // the two half-waves hold the same channel
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (hh == 0) {
+          st_lds[(wave * 64 + n * 32 + r) * 2] = ssum;
+          st_lds[(wave * 64 + n * 32 + r) * 2 + 1] = ssq;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid >> 1, k = tid & 1, co = nt * CM_BN + ch;
+      if (co < a.Cout) {
+        const float t = (st_lds[(0 * 64 + ch) * 2 + k] + st_lds[(1 * 64 + ch) * 2 + k]) +
+                        (st_lds[(2 * 64 + ch) * 2 + k] + st_lds[(3 * 64 + ch) * 2 + k]);
+        atomicAdd(a.stats + ((int64_t)b * a.stats_ld + co) * 2 + k, (double)t);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant for ks == 1 (plain GEMMs: 1x1 skip convs, NIN, attention contractions).  Only 24 MFMAs separate two
+// barriers there, too little to hide a DMA group, so B fragments go straight from L2 to registers (one coalesced
+// 1 KiB load per fragment, fetched a step ahead) and LDS holds only the double-buffered A tile.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int MT>
+struct CmGeoRegB {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int CH = (KS == 3) ? 1 : 2;          // k16 steps per LDS chunk
+  static constexpr int KCH = 16 * CH;                   // input channels per LDS chunk
+  static constexpr int ROWS = 4 * MT;
+  static constexpr int PW = 32 + KS - 1;
+  static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
+  static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
+  static constexpr int BUF = CH * PLANE;                // [k16 s]
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
+  static constexpr int ITEMS = P * Q;
+  static constexpr int NLOAD = (ITEMS + 255) / 256;
+  static constexpr int STEPS = TAPS * CH;               // MFMA steps (tap, s) per chunk
+  static constexpr int RING = (KS == 3) ? 3 : 2;        // B fragment register ring (prefetch distance RING-1)
+};
+template <int KS, int MT, int PRO>
+__global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
+                                                       unsigned nblocks) {
+  using G = CmGeoRegB<KS, MT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+
+  // ---- XCD-aware bijective remap: consecutive logical ids share an XCD (blocks i, i+8 are co-resident on one XCD)
+  unsigned lid;
+  {
+    const unsigned orig = blockIdx.x, xcd = orig & 7u, q = nblocks >> 3, rem = nblocks & 7u;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  }
+  const int nt = lid % ntiles;                  // output-channel tile fastest: sharers of one A tile are neighbours
+  const unsigned rest = lid / ntiles;
+  const int tile = rest % tiles_per_img;
+  const int b = rest / tiles_per_img;
+
+  const int64_t HW = (int64_t)a.H * a.W;
+  int ty0 = 0, tx0 = 0;
+  int64_t flat0 = 0;
+  if (KS == 3) {
+    ty0 = (tile / tiles_x) * G::ROWS;
+    tx0 = (tile % tiles_x) * 32;
+  } else {
+    flat0 = (int64_t)tile * G::P;
+  }
+  const float* xb = a.x + (int64_t)b * HW * a.ldx;
+  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * k16s * (G::TAPS * CM_BSTEP) + r * 32 + ((hh ^ ((r >> 3) & 1)) << 4);   // packed halves are pre-swizzled (LDS image of the DMA path)
   const float* psc = a.pro_scale + (int64_t)b * a.pro_ld;
   const float* psh = a.pro_shift + (int64_t)b * a.pro_ld;
   const int nchunks = (k16s + G::CH - 1) / G::CH;
@@ -361,7 +680,8 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
       hi[j] = h;
       lo[j] = (__bf16)(v - (float)h);
     }
-    char* base = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP + co_l * 32 + h2 * 16;
+    char* base = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP + co_l * 32 +
+                 ((h2 ^ ((co_l >> 3) & 1)) << 4);   // 16-B halves swapped on rows with bit 3 set: the image is copied verbatim to LDS
     *(bf16x8*)base = hi;
     *(bf16x8*)(base + CM_BPLANE) = lo;
   }
@@ -369,7 +689,7 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 
 extern "C" int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout) {
   if ((ks != 1 && ks != 3) || Cin <= 0 || Cout <= 0) return -1;
-  return mud_cdiv(Cout, CM_BN) * mud_cdiv(Cin, 16) * (int64_t)ks * ks * CM_BSTEP;
+  return mud_cdiv(Cout, CM_BN) * mud_cdiv(Cin, 16) * (int64_t)ks * ks * CM_BSTEP + 2 * CM_BSTEP;   // + slack: the last DMA group of a 1x1 operand with an odd number of 16-channel chunks reads one step past the end
 }
 
 extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride, int ks,
@@ -389,10 +709,11 @@ extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, i
 
 template <int KS, int MT, int PRO>
 static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
-  using G = CmGeo<KS, MT>;
+  using G = typename std::conditional<KS == 3, CmGeo<KS, MT>, CmGeoRegB<KS, MT>>::type;
+  const void* kfn = (KS == 3) ? (const void*)k_conv_mfma<KS, MT, PRO> : (const void*)k_conv_mfma_regb<KS, MT, PRO>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_mfma<KS, MT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
@@ -410,8 +731,12 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   }
   const int64_t nblocks = tiles * ntiles * a.B;
   MUD_REQUIRE(nblocks <= 0x7fffffff, "mud_conv2d_mfma: grid too large");
-  hipLaunchKernelGGL((k_conv_mfma<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
-                     (unsigned)nblocks);
+  if (KS == 3)
+    hipLaunchKernelGGL((k_conv_mfma<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
+                       (unsigned)nblocks);
+  else
+    hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
+                       (unsigned)nblocks);
   MUD_CHECK_LAUNCH("mud_conv2d_mfma");
   return MUD_OK;
 }

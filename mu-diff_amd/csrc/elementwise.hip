@@ -173,9 +173,59 @@ __global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ s, int
   }
 }
 
+// rows of up to 256*4*SM_V floats (n % 4 == 0) held in registers: one read, one write
+#define SM_V 4
+__global__ __launch_bounds__(256) void k_softmax_rows_reg(float* __restrict__ s, int64_t rows, int n, int ld) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    float* row = s + r * (int64_t)ld;
+    f32x4 v[SM_V];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SM_V; ++k) {
+      const int i = (k * 256 + threadIdx.x) * 4;
+      if (i < n) {
+        v[k] = *(const f32x4*)(row + i);
+        m = fmaxf(fmaxf(fmaxf(m, v[k][0]), fmaxf(v[k][1], v[k][2])), v[k][3]);
+      }
+    }
+    m = mud_wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_V; ++k) {
+      if ((k * 256 + threadIdx.x) * 4 < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k][e] = expf(v[k][e] - m); sum += v[k][e]; }
+      }
+    }
+    sum = mud_wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < SM_V; ++k) {
+      const int i = (k * 256 + threadIdx.x) * 4;
+      if (i < n) *(f32x4*)(row + i) = v[k] * inv;
+    }
+  }
+}
+
 extern "C" int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* stream) {
   MUD_REQUIRE(s && rows >= 0 && n > 0 && ld >= n, "mud_softmax_rows: bad args");
   if (rows == 0) return MUD_OK;
+  if (n % 4 == 0 && ld % 4 == 0 && n <= 256 * 4 * SM_V && mud_aligned16(s)) {
+    const int grid = (int)(rows < 256 * 32 ? rows : 256 * 32);
+    hipLaunchKernelGGL(k_softmax_rows_reg, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, rows, n, ld);
+    MUD_CHECK_LAUNCH("mud_softmax_rows");
+    return MUD_OK;
+  }
   const int grid = (int)(rows < 256 * 32 ? rows : 256 * 32);
   hipLaunchKernelGGL(k_softmax_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, rows, n, ld);
   MUD_CHECK_LAUNCH("mud_softmax_rows");

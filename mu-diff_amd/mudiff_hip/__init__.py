@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libmudiff_hip.so')
+_LIB_PATH = os.environ.get('MUDIFF_HIP_LIB', os.path.join(_HERE, 'libmudiff_hip.so'))   # override: kernel experiments
 _lib = None
 
 ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_SILU = 0, 1, 2, 3

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, name), f'{name} declared in include/mudiff_hip.h but not exported'
     assert sorted(mudiff_hip.EXPORTED_SYMBOLS) == declared, 'ctypes binding and header disagree'
     assert lib.mud_version() >= 100
-    assert lib.mud_packed_weight_bytes(3, 64, 64) == 1 * 2 * 9 * 4 * 64 * 32
+    assert lib.mud_packed_weight_bytes(3, 64, 64) == 1 * 4 * 9 * 4096 + 8192   # tiles * k16 chunks * taps * (hi+lo planes) + DMA slack
     assert lib.mud_packed_weight_bytes(2, 64, 64) == -1
     assert lib.mud_gn_ws_bytes(1, 65536, 256, 32) > 0
 
