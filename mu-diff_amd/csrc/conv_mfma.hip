@@ -36,28 +36,33 @@
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
 #define CM_PIX 80                // LDS bytes per pixel record of the A tile
 
-template <int KS, int MT>
+template <int KS, int MT, int WM, int WN>
 struct CmGeo {
+  static constexpr int NT = 64 * WM * WN;               // threads per workgroup
   static constexpr int TAPS = KS * KS;
   static constexpr int CH = (KS == 3) ? 1 : 2;          // k16 steps per LDS chunk
   static constexpr int KCH = 16 * CH;                   // input channels per LDS chunk
-  static constexpr int ROWS = 4 * MT;
+  static constexpr int ROWS = WM * MT;
   static constexpr int PW = 32 + KS - 1;
-  static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
+  static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 32 * WM * MT;
   static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
   static constexpr int BUF = CH * PLANE;                // [k16 s]
-  static constexpr int LDS_BYTES = 2 * BUF + 2 * ((KS == 3) ? 3 : 2) * CM_BSTEP;   // A double buffer + B ring (2 groups)
   static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
   static constexpr int ITEMS = P * Q;
-  static constexpr int NLOAD = (ITEMS + 255) / 256;
+  static constexpr int NLOAD = (ITEMS + NT - 1) / NT;
   static constexpr int STEPS = TAPS * CH;               // MFMA steps (tap, s) per chunk
   static constexpr int GS = (KS == 3) ? 3 : 2;          // steps per B group (one DMA batch, one barrier)
   static constexpr int NG = STEPS / GS;                 // B groups per chunk
-  static constexpr int GB = GS * CM_BSTEP;              // bytes per B group (contiguous in the packed weights)
+  static constexpr int GB1 = GS * CM_BSTEP;             // bytes per B group of ONE 64-channel tile (contiguous in the packed weights)
+  static constexpr int GB = WN * GB1;                   // bytes per B group of the workgroup (WN tiles)
+  static constexpr int PIECES = GB / 1024;              // 1 KiB DMA pieces per group
   static constexpr int A_BYTES = 2 * BUF;
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
-  static constexpr int LDS_TOTAL = A_BYTES + 2 * GB;
+  static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
+  static constexpr int LDS_BYTES = (A_BYTES + 2 * GB) > EP_BYTES ? (A_BYTES + 2 * GB) : EP_BYTES;
+  static_assert(NT % Q == 0 && PIECES % (WM * WN) == 0, "staging / DMA split");
 };
+
 
 
 __device__ __forceinline__ bool mud_dev_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
@@ -67,12 +72,13 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
-template <int KS, int MT, int PRO>
-__global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
-                                                       unsigned nblocks) {
-  using G = CmGeo<KS, MT>;
+template <int KS, int MT, int WM, int WN, int PRO>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
+                                                                unsigned nblocks) {
+  using G = CmGeo<KS, MT, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles
 
   // ---- XCD-aware bijective remap: consecutive logical ids share an XCD (blocks i, i+8 are co-resident on one XCD)
   unsigned lid;
@@ -95,7 +101,8 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
     flat0 = (int64_t)tile * G::P;
   }
   const float* xb = a.x + (int64_t)b * HW * a.ldx;
-  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * k16s * (G::TAPS * CM_BSTEP);
+  const int64_t tile_bytes = (int64_t)k16s * (G::TAPS * CM_BSTEP);          // packed bytes of one 64-channel tile
+  const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * WN * tile_bytes;
   const float* psc = a.pro_scale + (int64_t)b * a.pro_ld;
   const float* psh = a.pro_shift + (int64_t)b * a.pro_ld;
   const int nchunks = (k16s + G::CH - 1) / G::CH;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   unsigned vmask = 0;                           // bit j: slot j is a real (non-padding) pixel
 #pragma unroll
   for (int j = 0; j < G::NLOAD; ++j) {
-    const int item = (tid + j * 256) % G::ITEMS;   // 256 % Q == 0 and ITEMS % Q == 0: q is preserved
+    const int item = (tid + j * G::NT) % G::ITEMS;   // NT % Q == 0 and ITEMS % Q == 0: q is preserved
     const int p = item / G::Q;
     bool valid;
     int64_t g;
@@ -167,18 +174,19 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   char* const bring = smem + G::B_OFF;
   auto dma_b = [&](int gg) {                    // group gg -> ring slot gg & 1
     if (gg >= total_groups) return;             // wave-uniform
-    const char* src = wb + (int64_t)gg * G::GB + lane * 16;
     char* dst = bring + (gg & 1) * G::GB;
 #pragma unroll
-    for (int j = 0; j < G::GB / 4096; ++j) {
-      const int piece = wave + 4 * j;           // wave-uniform 1 KiB piece
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+    for (int j = 0; j < G::PIECES / (WM * WN); ++j) {
+      const int piece = wave + WM * WN * j;     // wave-uniform 1 KiB piece of the group image [WN tiles][GS steps][hi|lo][2 KiB]
+      const int t64 = piece / (G::GB1 / 1024), within = piece % (G::GB1 / 1024);
+      const char* src = wb + t64 * tile_bytes + (int64_t)gg * G::GB1 + within * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
     }
   };
   const int lane_b = r * 32 + ((hh ^ ((r >> 3) & 1)) << 4);   // this lane's 16 B inside a [32 co][32 B] fragment image
 
-  const int lane_a = ((KS == 3) ? (wave * MT * G::PW + r) : (wave * MT * 32 + r)) * CM_PIX + hh * 16;
+  const int lane_a = ((KS == 3) ? (wm * MT * G::PW + r) : (wm * MT * 32 + r)) * CM_PIX + hh * 16;
   f32x16 acc[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
       const int gg = kc * G::NG + g;
       dma_b(gg + 1);                            // next group's weights stream in under this group's MFMAs
       if (g == 0 && more) fetch_a(kc + 1);
-      const char* bcur = bring + (gg & 1) * G::GB;
+      const char* bcur = bring + (gg & 1) * G::GB + wn * G::GB1;
 #pragma unroll
       for (int sg = 0; sg < G::GS; ++sg) {
         const int st = g * G::GS + sg;          // step inside the chunk: KS=3: tap; KS=1: k16 half
@@ -242,16 +250,16 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   // tile instead of 16 scalar ones); the same pass folds the per-channel GroupNorm statistics.
   constexpr int EP_LD = 36;                                     // floats per staged pixel row (16-B aligned, bank-spread)
   float* ep = (float*)smem + wave * (32 * EP_LD);               // the A buffers are dead after the last barrier
-  float* st_lds = (float*)smem + 4 * (32 * EP_LD);              // [wave][64 ch][2]
+  float* st_lds = (float*)smem + WM * WN * (32 * EP_LD);        // [wave][64 ch][2]
   const bool vec = ((a.Cout | a.ldo | (a.res ? a.ldr : 0)) & 3) == 0 && mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res));
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int co = nt * CM_BN + n * 32 + r;
+    const int co = (nt * WN + wn) * CM_BN + n * 32 + r;
     const bool cok = co < a.Cout;
     float badd = (a.bias && cok) ? a.bias[co] : 0.f;
     if (a.bias2 && cok) badd += a.bias2[(int64_t)b * a.bias2_ld + co];
     if (vec) {
-      const int col = (lane & 7) * 4, co4 = nt * CM_BN + n * 32 + col;   // this lane's 4 channels in the read-back phase
+      const int col = (lane & 7) * 4, co4 = (nt * WN + wn) * CM_BN + n * 32 + col;   // this lane's 4 channels in the read-back phase
       f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
           int64_t opix;
           bool valid;
           if (KS == 3) {
-            const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
+            const int gy = ty0 + wm * MT + m, gx = tx0 + prow;
             valid = gy < a.H && gx < a.W;
             opix = ((int64_t)b * a.H + gy) * a.W + gx;
             if (a.sub2) {
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
               opix = ((int64_t)b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1);
             }
           } else {
-            const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
+            const int64_t fp = flat0 + (wm * MT + m) * 32 + prow;
             valid = fp < HW;
             opix = (int64_t)b * HW + fp;
           }
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
           int64_t opix;
           bool valid;
           if (KS == 3) {
-            const int gy = ty0 + wave * MT + m, gx = tx0 + prow;
+            const int gy = ty0 + wm * MT + m, gx = tx0 + prow;
             valid = gy < a.H && gx < a.W;
             opix = ((int64_t)b * a.H + gy) * a.W + gx;
             if (a.sub2) {
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
               opix = ((int64_t)b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1);
             }
           } else {
-            const int64_t fp = flat0 + (wave * MT + m) * 32 + prow;
+            const int64_t fp = flat0 + (wm * MT + m) * 32 + prow;
             valid = fp < HW;
             opix = (int64_t)b * HW + fp;
           }
@@ -345,11 +353,12 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma(mud_conv_a
   }
   if (a.stats) {
     __syncthreads();
-    if (tid < 128) {
-      const int ch = tid >> 1, k = tid & 1, co = nt * CM_BN + ch;
+    if (tid < 128 * WN) {
+      const int tn = tid >> 7, ch = (tid & 127) >> 1, k = tid & 1, co = (nt * WN + tn) * CM_BN + ch;
       if (co < a.Cout) {
-        const float t = (st_lds[(0 * 64 + ch) * 2 + k] + st_lds[(1 * 64 + ch) * 2 + k]) +
-                        (st_lds[(2 * 64 + ch) * 2 + k] + st_lds[(3 * 64 + ch) * 2 + k]);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) t += st_lds[((tn * WM + w) * 64 + ch) * 2 + k];   // the WM waves that share this channel tile
         atomicAdd(a.stats + ((int64_t)b * a.stats_ld + co) * 2 + k, (double)t);
       }
     }
@@ -707,10 +716,10 @@ extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, i
   return MUD_OK;
 }
 
-template <int KS, int MT, int PRO>
+template <int KS, int MT, int WM, int WN, int PRO>
 static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
-  using G = typename std::conditional<KS == 3, CmGeo<KS, MT>, CmGeoRegB<KS, MT>>::type;
-  const void* kfn = (KS == 3) ? (const void*)k_conv_mfma<KS, MT, PRO> : (const void*)k_conv_mfma_regb<KS, MT, PRO>;
+  using G = typename std::conditional<KS == 3, CmGeo<KS, MT, WM, WN>, CmGeoRegB<KS, MT>>::type;
+  const void* kfn = (KS == 3) ? (const void*)k_conv_mfma<KS, MT, WM, WN, PRO> : (const void*)k_conv_mfma_regb<KS, MT, PRO>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -720,20 +729,20 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
     }
     attr_set = true;
   }
-  const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN);
+  const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN * WN);
   int tiles_x = 1;
   int64_t tiles;
   if (KS == 3) {
     tiles_x = (int)mud_cdiv(a.W, 32);
-    tiles = (int64_t)tiles_x * mud_cdiv(a.H, G::ROWS);
+    tiles = (int64_t)tiles_x * mud_cdiv(a.H, WM * MT);
   } else {
     tiles = mud_cdiv((int64_t)a.H * a.W, G::P);
   }
   const int64_t nblocks = tiles * ntiles * a.B;
   MUD_REQUIRE(nblocks <= 0x7fffffff, "mud_conv2d_mfma: grid too large");
   if (KS == 3)
-    hipLaunchKernelGGL((k_conv_mfma<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
-                       (unsigned)nblocks);
+    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO>), dim3((unsigned)nblocks), dim3(64 * WM * WN), G::LDS_BYTES, s, a, tiles_x, (int)tiles,
+                       ntiles, k16s, (unsigned)nblocks);
   else
     hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
                        (unsigned)nblocks);
@@ -741,12 +750,12 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   return MUD_OK;
 }
 
-template <int KS, int MT>
+template <int KS, int MT, int WM = 4, int WN = 1>
 static int cm_launch(const mud_conv_args& a, hipStream_t s) {
   switch (a.pro_mode) {
-    case MUD_PRO_NONE: return cm_launch_pro<KS, MT, MUD_PRO_NONE>(a, s);
-    case MUD_PRO_AFFINE: return cm_launch_pro<KS, MT, MUD_PRO_AFFINE>(a, s);
-    default: return cm_launch_pro<KS, MT, MUD_PRO_AFFINE_SILU>(a, s);
+    case MUD_PRO_NONE: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_NONE>(a, s);
+    case MUD_PRO_AFFINE: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_AFFINE>(a, s);
+    default: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_AFFINE_SILU>(a, s);
   }
 }
 
@@ -775,12 +784,17 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   const int64_t ntiles = mud_cdiv(a.Cout, CM_BN);
   static const int force_mt = getenv("MUD_CONV_MT") ? atoi(getenv("MUD_CONV_MT")) : 0;   // tuning knob
   if (force_mt) {
-    if (a.ks == 3) return force_mt == 4 ? cm_launch<3, 4>(a, s) : force_mt == 2 ? cm_launch<3, 2>(a, s) : cm_launch<3, 1>(a, s);
+    if (a.ks == 3) return (force_mt == 8 && ntiles % 2 == 0) ? cm_launch<3, 2, 4, 2>(a, s) : force_mt == 1 ? cm_launch<3, 1>(a, s) : cm_launch<3, 2>(a, s);
     return force_mt == 4 ? cm_launch<1, 4>(a, s) : force_mt == 2 ? cm_launch<1, 2>(a, s) : cm_launch<1, 1>(a, s);
   }
   // Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
   // beats MT=4 (one workgroup per CU) by 15-40 % on every layer shape; MT=1 only when MT=2 cannot give 2 blocks/CU.
   if (a.ks == 3) {
+    // 8-wave variant (8 rows x 32 px x 128 channels per workgroup, 4 x 2 waves): the staged input tile (GroupNorm +
+    // SiLU + split, the main non-MFMA cost) is shared by twice as many MFMAs; used when the layer has an even number
+    // of 64-channel tiles and still fills the chip
+    const int64_t blocks8 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * (ntiles / 2) * a.B;
+    if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) return cm_launch<3, 2, 4, 2>(a, s);
     const int64_t blocks2 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * ntiles * a.B;
     if (blocks2 >= 512 && a.H >= 8) return cm_launch<3, 2>(a, s);
     return cm_launch<3, 1>(a, s);

@@ -4,12 +4,12 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/mu-diff_amd')
 import torch
 from mudiff_hip import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-shapes = [  # H, Cin, Cout, ks
+shapes = [ s for s in [  # H, Cin, Cout, ks
     (256, 64, 64, 3), (256, 256, 64, 3), (256, 192, 64, 3), (256, 128, 64, 3), (256, 320, 64, 3), (256, 192, 384, 3),
     (128, 64, 128, 3), (128, 128, 128, 3), (128, 384, 128, 3), (128, 256, 128, 3), (128, 192, 128, 3),
     (64, 128, 256, 3), (64, 256, 256, 3), (64, 512, 256, 3), (64, 384, 256, 3),
     (256, 256, 64, 1), (128, 64, 128, 1), (64, 128, 256, 1), (64, 256, 768, 1), (64, 256, 256, 1), (64, 512, 256, 1), (128, 384, 128, 1),
-]
+] if (len(sys.argv) < 3 or s[2] % 128 == 0) ]
 dev = 'cuda:0'
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
