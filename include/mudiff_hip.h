@@ -140,7 +140,13 @@ int mud_fir_nhwc(const float* x, int B, int H, int W, int C, int ldx, const floa
                  const float* pro_scale, const float* pro_shift, int pro_ld, int pro_mode,
                  float* out_h, int ldh, float* out_x, int ldxo, void* stream);
 
-/* ---- attention pieces (layerspp.py:118-122) and the G2 feature fusion (…feat.py:769-788) */
+/* ---- fused attention (layerspp.py:118-122): out[b,i,:] = sum_j softmax_j(q_i.k_j * scale) v_j, single head.
+ * qkv: [B, N, ld] with q at +0, k at +C, v at +2C (the fused NIN_0|1|2 output); out [B, N, ldo].
+ * Flash-style (no N x N matrix in memory), split-bf16 MFMA.  Head dims: see mud_attention_supported(). */
+int mud_attention_supported(int C);
+int mud_attention(const float* qkv, int B, int N, int C, int ld, float scale, float* out, int ldo, void* stream);
+
+/* ---- unfused attention pieces (used when the head dim is not supported above) and the G2 feature fusion (…feat.py:769-788) */
 int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* stream);          /* in place */
 int mud_mul(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t npix, int C, void* stream);
 /* out = g*att + (1-g)*other; views are [B, hw, C]; optional per-channel stats of `out` as in mud_conv_args */

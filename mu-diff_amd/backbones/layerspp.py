@@ -145,6 +145,9 @@ class AttnBlockpp(nn.Module, _Prepared):
         c, n = self.channels, x.H * x.W
         sc, sh = ops.gn_scale_shift(x, self.GroupNorm_0.num_groups, p['gamma'], p['beta'])
         qkv = ops.conv(x, p['wqkv'], 1, 3 * c, mfma=True, pro=(sc, sh, PRO_AFFINE), bias=p['bqkv'])     # [B,H,W,3C]
+        if ops.attention_supported(c):      # fused flash-style kernel: the N x N score matrix is never materialised
+            h = ops.attention(qkv, c, float(int(c) ** (-0.5)))
+            return ops.conv(h, p['wo'], 1, c, mfma=True, bias=p['bo'], res=x, out_scale=INV_SQRT2 if self.skip_rescale else 1.0, out=out)
         q = View(qkv.base, x.B, 1, n, c, 3 * c, 0)
         # scores S[b,i,j] = q_i . k_j / sqrt(C): B operand = K rows ("co" = key index), per sample
         kp = ops.pack_weights(qkv.base, 0, 1, 3 * c, 1, c, n, nbatch=x.B, src_bstride=n * 3 * c, src_offset=c)

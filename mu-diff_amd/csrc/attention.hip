@@ -1,0 +1,275 @@
+// Fused single-head self-attention for AttnBlockpp (reference backbones/layerspp.py:118-122):
+//     out[b,i,:] = sum_j softmax_j(q_i . k_j * scale) v_j        N = H*W positions, head dim C <= 256
+// Flash-style: the N x N score matrix never exists in memory (the unfused path wrote, re-read twice and read
+// again 4*N*N bytes per sample).  Same split-bf16 arithmetic as the convolutions: every fp32 operand is
+// hi + lo bf16 and every product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//
+// One workgroup = 4 waves = 128 queries (32 per wave), one wave per SIMD (the kernel owns the register file:
+// Q as 2*C/16 B-fragments and the C x 32 output accumulator stay in registers for the whole key loop).
+// Everything is computed TRANSPOSED so that a query is a LANE (MFMA column) from start to finish:
+//     S^T[key, query] = K . Q^T         A = K tile (LDS, shared by the 4 waves), B = Q^T (registers)
+//     online softmax over keys          per lane: 16 accumulator registers + 1 shuffle with lane^32
+//     O^T[ch, query] += V^T . P^T       A = V^T tile (LDS, transposed + key-permuted on the way in),
+//                                       B = P^T = the S^T accumulator registers themselves (cdna guide:
+//                                       "an accumulator tile as the next MFMA's operand"), no LDS round trip
+// K / V tiles of 32 keys are double-buffered in LDS; the next tile's global loads are in flight (registers)
+// during the MFMAs of the current one; one barrier per tile.
+#include "mud_common.h"
+
+template <int C16>
+struct AtGeo {
+  static constexpr int C = 16 * C16;
+  static constexpr int CT = (C16 + 1) / 2;            // 32-channel output tiles
+  static constexpr int CP = CT * 32;                  // channels padded to a multiple of 32
+  static constexpr int KROW = C * 4 + 16;             // LDS bytes per key row: [hi C x bf16 | lo C x bf16 | pad]
+  static constexpr int VROW = 144;                    // LDS bytes per channel row: [hi 32 keys | lo 32 keys | pad]
+  static constexpr int KT = 32 * KROW, VT = CP * VROW;
+  static constexpr int BUF = KT + VT;
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int KITEMS = 32 * (C / 4), KN = (KITEMS + 255) / 256;   // float4 loads per thread for a K tile
+  static constexpr int VITEMS = CP * 8, VN = (VITEMS + 255) / 256;         // 4-key groups per thread for a V tile
+};
+
+template <int C16>
+__global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ qkv, int N, int ld, float scale_log2,
+                                                       float* __restrict__ out, int ldo) {
+  using G = AtGeo<C16>;
+  constexpr int C = G::C, CT = G::CT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * 128 + wave * 32 + r;              // this lane's query (both half-waves hold the same 32 queries)
+  const float* base = qkv + (int64_t)b * N * ld;
+  const int ntiles = (N + 31) / 32;
+
+  // ---- Q^T B-fragments, split once: lane (query r, k half hh) holds channels 16s + 8hh .. +7 of its query
+  bf16x8 qh[C16], ql[C16];
+#pragma unroll
+  for (int s = 0; s < C16; ++s) {
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (qi < N) {
+      const float* qp = base + (int64_t)qi * ld + 16 * s + 8 * hh;
+      v0 = *(const f32x4*)qp;
+      v1 = *(const f32x4*)(qp + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
+      qh[s][e] = h0; qh[s][4 + e] = h1;
+      ql[s][e] = (__bf16)(v0[e] - (float)h0); ql[s][4 + e] = (__bf16)(v1[e] - (float)h1);
+    }
+  }
+
+  // ---- staging loads through a buffer descriptor: ONE per-lane byte offset per stream (K, V) + scalar (SGPR) tile /
+  // row offsets, and keys >= N (or padded channels) fall outside the descriptor's range and read as 0 - no
+  // per-load address registers, no predication.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((int64_t)N * ld * 4 < 0x7fffffffLL ? (int64_t)N * ld * 4 : 0x7fffffffLL), 0x00020000);
+  constexpr int KJ = 256 / (C / 4);                    // key rows covered by one pass of the 256 threads (K stream)
+  constexpr int VG = 256 / G::CP;                      // 4-key groups covered by one pass (V stream)
+  const unsigned OOR = 0x7ffffff0u;                    // out-of-range offset -> reads 0
+  const unsigned kvoff = (tid < G::KITEMS) ? (unsigned)(((tid / (C / 4)) * ld + C + 4 * (tid % (C / 4))) * 4) : OOR;
+  const unsigned vvoff = ((tid % G::CP) < C && tid < G::VITEMS) ? (unsigned)((2 * C + (tid % G::CP)) * 4) : OOR;
+  f32x4 kraw[G::KN];
+  float vraw[G::VN][4];
+  auto fetch_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < G::KN; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff, (kt * 32 + KJ * i) * ld * 4, 0);
+      kraw[i] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto fetch_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < G::VN; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int gkey = 4 * (tid / G::CP + VG * i) + u;            // key inside the tile (the per-lane part is 0 when CP == 256)
+        vraw[i][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vvoff + (unsigned)((4 * (tid / G::CP)) * ld * 4),
+                                                                                 (kt * 32 + 4 * VG * i + u) * ld * 4, 0));
+        (void)gkey;
+      }
+    }
+  };
+  auto stash_k = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < G::KN; ++i) {
+      const int item = tid + 256 * i, j = item / (C / 4), c4 = item % (C / 4);
+      if (item < G::KITEMS) {
+        const bf16x4 hi = __builtin_convertvector(kraw[i], bf16x4);
+        const bf16x4 lo = __builtin_convertvector(kraw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+        *(bf16x4*)(buf + j * G::KROW + c4 * 8) = hi;
+        *(bf16x4*)(buf + j * G::KROW + C * 2 + c4 * 8) = lo;
+      }
+    }
+  };
+  auto stash_v = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < G::VN; ++i) {
+      const int item = tid + 256 * i, c = item % G::CP, g = item / G::CP;
+      if (item < G::VITEMS) {
+        // keys 4g..4g+3 of the tile -> k-step s, lane half h, element block: the order in which the S^T accumulator
+        // registers enumerate keys (element e of half h of step s is key 16s + 8(e>>2) + 4h + (e&3))
+        const int jj = (4 * g) & 15, s = (4 * g) >> 4, h = (jj >> 2) & 1, blk = (jj >> 3) & 1;
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const __bf16 t = (__bf16)vraw[i][u];
+          hi[u] = t;
+          lo[u] = (__bf16)(vraw[i][u] - (float)t);
+        }
+        char* p = buf + G::KT + c * G::VROW + s * 32 + h * 16 + blk * 8;
+        *(bf16x4*)p = hi;
+        *(bf16x4*)(p + 64) = lo;
+      }
+    }
+  };
+
+  f32x16 o[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[ct][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  fetch_k(0);
+  stash_k(smem);
+  fetch_v(0);
+  stash_v(smem);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const char* cur = smem + (kt & 1) * G::BUF;
+    char* nxt = smem + ((kt + 1) & 1) * G::BUF;
+    const bool more = kt + 1 < ntiles;
+    if (more) fetch_k(kt + 1);          // next K tile: in flight during S^T, parked in LDS right after it
+
+    // ---- S^T = K . Q^T
+    f32x16 st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < C16; ++s) {
+      const char* kp = cur + r * G::KROW + (16 * s + 8 * hh) * 2;
+      const bf16x8 kh = *(const bf16x8*)kp;
+      const bf16x8 kl = *(const bf16x8*)(kp + C * 2);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
+      if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads from piling up in registers
+    }
+    if (more) {
+      stash_k(nxt);
+      fetch_v(kt + 1);                  // next V tile: in flight during softmax + PV (same registers' time slot)
+    }
+
+    // ---- online softmax over the 32 keys of the tile (log2 domain); register i of half hh is key (i&3)+8(i>>2)+4hh
+    float mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      st[i] = key < N ? st[i] * scale_log2 : -INFINITY;
+      mt = fmaxf(mt, st[i]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);                    // finite: every tile holds at least one real key
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = __builtin_amdgcn_exp2f(st[i] - m_new);
+      psum += st[i];
+    }
+    l_run = l_run * alpha + psum;                            // per-lane partial (its 16 keys); halves are added at the end
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[ct][i] *= alpha;
+    }
+
+    // ---- P^T B-fragments straight from the accumulator registers: step s2 = registers 8*s2 .. 8*s2+7
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float p = st[8 * s2 + e];
+        const __bf16 t = (__bf16)p;
+        ph[s2][e] = t;
+        pl[s2][e] = (__bf16)(p - (float)t);
+      }
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const char* vp = cur + G::KT + (ct * 32 + r) * G::VROW + s2 * 32 + hh * 16;
+        const bf16x8 vh = *(const bf16x8*)vp;
+        const bf16x8 vl = *(const bf16x8*)(vp + 64);
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[ct], 0, 0, 0);
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[ct], 0, 0, 0);
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[ct], 0, 0, 0);
+      }
+      if ((ct & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (more) stash_v(nxt);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane = query, register i of tile ct is channel ct*32 + (i&3) + 8(i>>2) + 4hh
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qi < N) {
+    float* op = out + ((int64_t)b * N + qi) * ldo;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int c0 = ct * 32 + 8 * q4 + 4 * hh;
+        if (c0 < C) {
+          f32x4 v = {o[ct][4 * q4] * inv, o[ct][4 * q4 + 1] * inv, o[ct][4 * q4 + 2] * inv, o[ct][4 * q4 + 3] * inv};
+          *(f32x4*)(op + c0) = v;
+        }
+      }
+  }
+}
+
+template <int C16>
+static int at_launch(const float* qkv, int B, int N, int ld, float scale, float* out, int ldo, hipStream_t s) {
+  using G = AtGeo<C16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_attention<C16>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      mud_set_error("mud_attention: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
+      return MUD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_attention<C16>), dim3((unsigned)mud_cdiv(N, 128), B), dim3(256), G::LDS_BYTES, s, qkv, N, ld,
+                     scale * 1.44269504088896340736f, out, ldo);
+  MUD_CHECK_LAUNCH("mud_attention");
+  return MUD_OK;
+}
+
+extern "C" int mud_attention_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128 || C == 256; }
+
+extern "C" int mud_attention(const float* qkv, int B, int N, int C, int ld, float scale, float* out, int ldo, void* stream) {
+  MUD_REQUIRE(qkv && out, "mud_attention: null pointer");
+  MUD_REQUIRE(B >= 0 && B <= 65535 && N > 0 && ld >= 3 * C && ldo >= C, "mud_attention: bad sizes");
+  MUD_REQUIRE(mud_attention_supported(C), "mud_attention: head dim %d not in {16,32,64,128,256}", C);
+  MUD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && mud_aligned16(qkv) && mud_aligned16(out), "mud_attention: needs ld %% 4 == 0 and 16-byte aligned buffers");
+  if (B == 0) return MUD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 16: return at_launch<1>(qkv, B, N, ld, scale, out, ldo, s);
+    case 32: return at_launch<2>(qkv, B, N, ld, scale, out, ldo, s);
+    case 64: return at_launch<4>(qkv, B, N, ld, scale, out, ldo, s);
+    case 128: return at_launch<8>(qkv, B, N, ld, scale, out, ldo, s);
+    default: return at_launch<16>(qkv, B, N, ld, scale, out, ldo, s);
+  }
+}

@@ -339,6 +339,20 @@ def fir_nhwc(x: View, kernel2d, up, down, pad, pro=None, want_h=True, want_x=Fal
     return oh, ox
 
 
+def attention_supported(C_):
+    return bool(load().mud_attention_supported(C_))
+
+
+def attention(qkv: View, C_, scale):
+    """qkv: view [B,H,W,3C] (q | k | v, contiguous rows) -> View [B,H,W,C]."""
+    assert qkv.C == 3 * C_
+    n = qkv.H * qkv.W
+    out = View.empty(qkv.B, qkv.H, qkv.W, C_, qkv.device)
+    _launch('attention', load().mud_attention, qkv.ptr, qkv.B, n, C_, qkv.ld, float(scale), out.ptr, out.ld, stream_ptr(),
+            flops=4.0 * qkv.B * n * n * C_)
+    return out
+
+
 def softmax_rows_(s, n):
     """in-place softmax over the last axis of a contiguous [..., n] tensor."""
     rows = s.numel() // n

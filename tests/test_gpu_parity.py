@@ -220,6 +220,27 @@ def test_softmax_and_gates():
         assert maxdiff(out.stats[..., 0], ref.sum(dim=(2, 3))) < 1e-4
 
 
+@pytest.mark.parametrize('B,H,W,C', [(2, 8, 8, 16), (1, 6, 6, 32), (2, 16, 16, 64), (1, 64, 64, 256), (2, 12, 10, 128), (1, 8, 8, 48)])
+def test_attention_block_fused_and_unfused(B, H, W, C):
+    """AttnBlockpp on the fused flash kernel (C in 16/32/64/128/256) and on the unfused GEMM + softmax path (C = 48),
+    against the oracle; key counts that are not multiples of the 32-key tile exercise the tail masking."""
+    ops, S, L, *_ = _imports()
+    gen = torch.Generator().manual_seed(C + H)
+    m = L.AttnBlockpp(C, skip_rescale=True, init_scale=0.)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if v.dim() == 2:
+            sd[k] = (torch.rand(v.shape, generator=gen) * 2 - 1) * math.sqrt(3.0 / v.shape[0])
+        else:
+            sd[k] = 0.1 * torch.randn(v.shape, generator=gen) + (1.0 if k.endswith('GroupNorm_0.weight') else 0.0)
+    m.load_state_dict(sd)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.5
+    ref = O.attn_block({'m.' + k: v for k, v in sd.items()}, 'm', x)
+    err = maxdiff(m.to(DEV)(g(x)), ref)
+    print(f'attention {B}x{H}x{W} C={C}: {err:.2e}')
+    assert err < 5e-5
+
+
 def test_blocks_against_reference_golden():
     ops, S, L, UD, *_ = _imports()
     import torch.nn as nn
