@@ -106,6 +106,18 @@ def cpu_baseline(cfg):
                        f'{dt:.2f} s; torch {torch.__version__} CPU fp32')
 
 
+def traffic_from_profiles():
+    """HBM bytes per launch of the dominant kernel from the latest committed PMC passes (profiles/rNN_*_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, gfx950 correction applied).  rocprofv3 cannot run
+    inside the timed process, so the committed measurement is reported, or null when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_traffic.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get('dominant_hbm_bytes_per_launch')
+
+
 def log(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
@@ -190,9 +202,10 @@ def main():
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
             line['roofline'] = {'kernel': 'k_conv_mfma<3> (3x3 implicit GEMM, split-bf16 MFMA)', 'bound': 'mfma',
                                 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                                'traffic': None,
+                                'traffic': traffic_from_profiles(),
                                 'launches': k['n'], 'avg_launch_us': round(1e3 * k['ms'] / k['n'], 2),
                                 'algorithmic_gflop_per_launch': round(k['flops'] / k['n'] / 1e9, 3),
+                                'algorithmic_bytes_per_launch': int(k['bytes'] / k['n']),
                                 'issued_bf16_tflops': round(3 * ach, 2), 'issued_frac': round(3 * ach / PEAK_BF16_TFLOPS, 4),
                                 'vs_fp32_peak_157.3': round(ach / PEAK_FP32_TFLOPS, 3),
                                 'share_of_gpu_time': round(k['ms'] / sum(v['ms'] for v in prof.values()), 3)}
