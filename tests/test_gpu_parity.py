@@ -328,6 +328,31 @@ def test_config2_full_size_every_step_vs_reference():
     assert abs(dp) <= 0.05 and abs(ds) <= 0.001
 
 
+@pytest.mark.parametrize('H,W,B,kw', [(40, 40, 3, dict(num_channels_dae=32, ch_mult=[1, 2, 4], attn_resolutions=(10,))),
+                                       (24, 56, 2, dict(num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(), num_res_blocks=1)),
+                                       (240, 240, 1, dict(num_channels_dae=32, ch_mult=[1, 2, 4], attn_resolutions=(60,), num_res_blocks=1))])
+def test_ragged_sizes_against_oracle(H, W, B, kw):
+    """Image sizes that are not multiples of the 8x32 conv tile / 32-key attention tile / 128-query block (240x240 is
+    what the reference trains on), odd batch sizes, non-square slices: one G1 + G2 + posterior step vs the oracle."""
+    ops, S, *_ = _imports()
+    cfg = O.default_config(image_size=H, **kw)
+    g1, g2 = _build(cfg, seed=5)
+    sd1, sd2 = O.make_state_dict(cfg, 'g1', 5), O.make_state_dict(cfg, 'g2', 5)
+    gen = torch.Generator().manual_seed(H * 7 + W)
+    x, c1, c2, c3 = (torch.tanh(torch.randn(B, 1, H, W, generator=gen)) for _ in range(4))
+    z, noise = torch.randn(B, cfg.nz, generator=gen), torch.randn(B, 1, H, W, generator=gen)
+    t = torch.randint(0, cfg.num_timesteps, (B,), generator=gen)
+    y1 = g1(g(x), g(c1), g(c2), g(c3), g(t), g(z))
+    y2 = g2(g(x), g(c1), g(c2), g(c3), g(t), g(z), y1)
+    xn = S.sample_posterior_combine(S.Posterior_Coefficients(cfg, DEV), y1, y2, g(x), g(t), g(noise))
+    r1 = O.g1_forward(sd1, cfg, x, c1, c2, c3, t, z)
+    r2 = O.g2_forward(sd2, cfg, x, c1, c2, c3, t, z, r1)
+    rn = O.sample_posterior_combine(O.PosteriorCoefficients(cfg), r1, r2, x, t, noise)
+    errs = (maxdiff(y1, r1), maxdiff(y2, r2), maxdiff(xn, rn))
+    print(f'{H}x{W} B={B}: {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}')
+    assert max(errs) <= 1e-3
+
+
 def test_graph_sampler_matches_eager_and_batches():
     ops, S, *_ = _imports()
     cfg = O.default_config(**SMALL_CFGS['s32'])
