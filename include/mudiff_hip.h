@@ -35,10 +35,12 @@ extern "C" {
 #define MUD_ACT_SIGMOID 1
 #define MUD_ACT_TANH 2
 #define MUD_ACT_SILU 3
+#define MUD_ACT_LRELU 4      /* LeakyReLU(0.2): the critic's activation (backbones/discriminator.py:178) */
 
 #define MUD_PRO_NONE 0         /* A operand used as stored                                   */
 #define MUD_PRO_AFFINE 1       /* a[b,c]*x + s[b,c]            (GroupNorm, AttnBlockpp)      */
 #define MUD_PRO_AFFINE_SILU 2  /* silu(a[b,c]*x + s[b,c])      (AdaGN + SiLU of the ResBlock) */
+#define MUD_PRO_LRELU 3        /* lrelu_0.2(x), no affine      (DownConvBlock of the critic)  */
 
 int mud_version(void);
 const char* mud_last_error(void);
@@ -139,6 +141,10 @@ int mud_fir_nhwc(const float* x, int B, int H, int W, int C, int ldx, const floa
                  int up, int down, int pad0, int pad1,
                  const float* pro_scale, const float* pro_shift, int pro_ld, int pro_mode,
                  float* out_h, int ldh, float* out_x, int ldxo, void* stream);
+
+/* ---- minibatch standard deviation of the critic (backbones/discriminator.py:246-254, stddev_feat = 1):
+ * x view [B, hw, C]; samples b = g*M + m (g < group, M = B/group); out[b] = mean_{c,p} sqrt(var_g(x[g*M+m,p,c]) + 1e-8) */
+int mud_minibatch_stddev(const float* x, int B, int64_t hw, int C, int ld, int group, float* out, void* stream);
 
 /* ---- fused attention (layerspp.py:118-122): out[b,i,:] = sum_j softmax_j(q_i.k_j * scale) v_j, single head.
  * qkv: [B, N, ld] with q at +0, k at +C, v at +2C (the fused NIN_0|1|2 output); out [B, N, ldo].

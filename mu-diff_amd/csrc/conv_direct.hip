@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
 #pragma unroll
           for (int u = 0; u < VI; ++u) {
             float v = xv[u];
-            if (a.pro_mode != MUD_PRO_NONE)
+            if (a.pro_mode == MUD_PRO_LRELU)
+              v = v > 0.f ? v : 0.2f * v;
+            else if (a.pro_mode != MUD_PRO_NONE)
               v = mud_prologue(v, a.pro_scale[(int64_t)b * a.pro_ld + ci + u], a.pro_shift[(int64_t)b * a.pro_ld + ci + u], a.pro_mode);
             const float* w = wp + (int64_t)(ci + u) * a.Cout;
             if (VO == 4) {
@@ -183,7 +185,7 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(a.B >= 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0 && a.ks >= 1 && a.stride >= 1 && a.pad >= 0,
               "mud_conv2d_direct: bad sizes");
   MUD_REQUIRE(a.ldx >= a.Cin && a.ldo >= a.Cout, "mud_conv2d_direct: ld smaller than C");
-  MUD_REQUIRE(a.pro_mode == MUD_PRO_NONE || (a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin), "mud_conv2d_direct: prologue arrays missing");
+  MUD_REQUIRE(a.pro_mode == MUD_PRO_NONE || a.pro_mode == MUD_PRO_LRELU || (a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin), "mud_conv2d_direct: prologue arrays missing");
   MUD_REQUIRE(!a.res || a.ldr >= a.Cout, "mud_conv2d_direct: bad residual view");
   const int Ho = (a.H + 2 * a.pad - a.ks) / a.stride + 1, Wo = (a.W + 2 * a.pad - a.ks) / a.stride + 1;
   MUD_REQUIRE(Ho > 0 && Wo > 0, "mud_conv2d_direct: empty output");

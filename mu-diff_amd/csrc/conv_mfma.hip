@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
-    if (PRO != MUD_PRO_NONE) {
+    if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
       psc_r = *(const f32x4*)(psc + c);
       psh_r = *(const f32x4*)(psh + c);
     }
@@ -151,12 +151,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
       f32x4 v = raw[j];
-      if (PRO != MUD_PRO_NONE) {
+      if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
         v = v * psc_r + psh_r;
         if (PRO == MUD_PRO_AFFINE_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
         }
+      } else if (PRO == MUD_PRO_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
       }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
-    if (PRO != MUD_PRO_NONE) {
+    if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
       psc_r = *(const f32x4*)(psc + c);
       psh_r = *(const f32x4*)(psh + c);
     }
@@ -464,12 +467,15 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
       f32x4 v = raw[j];
-      if (PRO != MUD_PRO_NONE) {
+      if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
         v = v * psc_r + psh_r;
         if (PRO == MUD_PRO_AFFINE_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
         }
+      } else if (PRO == MUD_PRO_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
       }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
@@ -755,6 +761,7 @@ static int cm_launch(const mud_conv_args& a, hipStream_t s) {
   switch (a.pro_mode) {
     case MUD_PRO_NONE: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_NONE>(a, s);
     case MUD_PRO_AFFINE: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_AFFINE>(a, s);
+    case MUD_PRO_LRELU: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_LRELU>(a, s);
     default: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_AFFINE_SILU>(a, s);
   }
 }
@@ -771,7 +778,8 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(a.ldo >= a.Cout && (!a.res || a.ldr >= a.Cout), "mud_conv2d_mfma: bad output/residual view");
   MUD_REQUIRE(!a.stats || a.stats_ld >= a.Cout, "mud_conv2d_mfma: bad stats view");
   MUD_REQUIRE(!a.sub2 || (a.ks == 3 && (a.H & 1) && (a.W & 1)), "mud_conv2d_mfma: sub2 needs ks == 3 and odd H, W");
-  if (a.pro_mode != MUD_PRO_NONE) {
+  MUD_REQUIRE(a.pro_mode >= MUD_PRO_NONE && a.pro_mode <= MUD_PRO_LRELU, "mud_conv2d_mfma: unknown prologue mode %d", a.pro_mode);
+  if (a.pro_mode == MUD_PRO_AFFINE || a.pro_mode == MUD_PRO_AFFINE_SILU) {
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),
                 "mud_conv2d_mfma: prologue arrays missing or misaligned");
   } else {

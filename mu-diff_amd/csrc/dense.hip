@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ in, int
         for (int j = 0; j < DENSE_BCHUNK; ++j) {
           if (b0 + j < B) {
             float v = in[(int64_t)(b0 + j) * ldi + k];
-            if (act_in == MUD_ACT_SILU) v = mud_silu(v);
+            if (act_in != MUD_ACT_NONE) v = mud_act(v, act_in);
             acc[j] = fmaf(wv, v, acc[j]);
           }
         }
@@ -42,7 +42,6 @@ extern "C" int mud_dense(const float* in, int ldi, const float* W, const float* 
                          int act_in, int act_out, void* stream) {
   MUD_REQUIRE(in && W && out, "mud_dense: null pointer");
   MUD_REQUIRE(B >= 0 && K > 0 && N > 0 && ldi >= K && ldo >= N, "mud_dense: bad sizes B=%d K=%d N=%d ldi=%d ldo=%d", B, K, N, ldi, ldo);
-  MUD_REQUIRE(act_in == MUD_ACT_NONE || act_in == MUD_ACT_SILU, "mud_dense: act_in must be none or silu");
   if (B == 0) return MUD_OK;
   int64_t blocks = mud_cdiv(N, 4);
   if (blocks > 2048) blocks = 2048;

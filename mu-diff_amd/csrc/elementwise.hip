@@ -317,3 +317,42 @@ extern "C" int mud_gate_mix(const float* g, int ldg, const float* att, int lda, 
   MUD_CHECK_LAUNCH("mud_gate_mix");
   return MUD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// minibatch standard deviation (backbones/discriminator.py:246-254): tiny (the critic's last feature map is 4x4)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minibatch_stddev(const float* __restrict__ x, int M, int64_t hw, int C, int ld, int group,
+                                                          float* __restrict__ out) {
+  __shared__ double red[4];
+  const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = hw * C;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int64_t p = i / C;
+    const int c = (int)(i % C);
+    float mean = 0.f;
+    for (int g = 0; g < group; ++g) mean += x[(((int64_t)g * M + m) * hw + p) * ld + c];
+    mean /= (float)group;
+    float var = 0.f;
+    for (int g = 0; g < group; ++g) {
+      const float d = x[(((int64_t)g * M + m) * hw + p) * ld + c] - mean;
+      var += d * d;
+    }
+    acc += (double)sqrtf(var / (float)group + 1e-8f);
+  }
+  acc = mud_wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+    for (int g = 0; g < group; ++g) out[g * M + m] = s;
+  }
+}
+
+extern "C" int mud_minibatch_stddev(const float* x, int B, int64_t hw, int C, int ld, int group, float* out, void* stream) {
+  MUD_REQUIRE(x && out, "mud_minibatch_stddev: null pointer");
+  MUD_REQUIRE(B > 0 && group > 0 && B % group == 0 && hw > 0 && C > 0 && ld >= C, "mud_minibatch_stddev: B=%d must be a multiple of group=%d", B, group);
+  hipLaunchKernelGGL(k_minibatch_stddev, dim3(B / group), dim3(256), 0, (hipStream_t)stream, x, B / group, hw, C, ld, group, out);
+  MUD_CHECK_LAUNCH("mud_minibatch_stddev");
+  return MUD_OK;
+}

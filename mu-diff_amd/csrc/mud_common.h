@@ -41,6 +41,7 @@ __device__ __forceinline__ float mud_act(float v, int act) {
     case MUD_ACT_SIGMOID: return mud_sigmoid(v);
     case MUD_ACT_TANH: return tanhf(v);
     case MUD_ACT_SILU: return mud_silu(v);
+    case MUD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
     default: return v;
   }
 }
@@ -53,11 +54,13 @@ __device__ __forceinline__ float mud_fast_silu(float v) {
 
 __device__ __forceinline__ float mud_prologue(float v, float sc, float sh, int mode) {
   if (mode == MUD_PRO_NONE) return v;
+  if (mode == MUD_PRO_LRELU) return v > 0.f ? v : 0.2f * v;
   v = fmaf(v, sc, sh);
   return mode == MUD_PRO_AFFINE_SILU ? mud_silu(v) : v;
 }
 __device__ __forceinline__ float mud_prologue_fast(float v, float sc, float sh, int mode) {
   if (mode == MUD_PRO_NONE) return v;
+  if (mode == MUD_PRO_LRELU) return v > 0.f ? v : 0.2f * v;
   v = fmaf(v, sc, sh);
   return mode == MUD_PRO_AFFINE_SILU ? mud_fast_silu(v) : v;
 }

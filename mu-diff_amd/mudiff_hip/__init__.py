@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('MUDIFF_HIP_LIB', os.path.join(_HERE, 'libmudiff_hip.so'))   # override: kernel experiments
 _lib = None
 
-ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_SILU = 0, 1, 2, 3
-PRO_NONE, PRO_AFFINE, PRO_AFFINE_SILU = 0, 1, 2
+ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_SILU, ACT_LRELU = 0, 1, 2, 3, 4
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_SILU, PRO_LRELU = 0, 1, 2, 3
 
 
 class MudiffHipError(RuntimeError):
@@ -60,6 +60,7 @@ _SIGNATURES = {
     'mud_conv2d_mfma': (_I, [C.POINTER(ConvArgs), _P]),
     'mud_upfirdn2d': (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mud_fir_nhwc': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
+    'mud_minibatch_stddev': (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     'mud_attention_supported': (_I, [_I]),
     'mud_attention': (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
     'mud_softmax_rows': (_I, [_P, _L, _I, _I, _P]),

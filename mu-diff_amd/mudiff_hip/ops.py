@@ -7,7 +7,7 @@ import math
 
 import torch
 
-from . import (ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE, PRO_AFFINE_SILU, PRO_NONE, ConvArgs,  # noqa: F401
+from . import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE, PRO_AFFINE_SILU, PRO_LRELU, PRO_NONE, ConvArgs,  # noqa: F401
                MudiffHipError, check, load, ptr, require_gpu, stream_ptr)
 
 
@@ -275,7 +275,9 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     a.x, a.B, a.H, a.W, a.Cin, a.ldx = x.ptr, x.B, x.H, x.W, x.C, x.ld
     a.w, a.w_bstride = ptr(w), w_bstride
     a.ks, a.stride, a.pad = ks, stride, pad
-    if pro is not None:
+    if pro is not None and pro[2] == PRO_LRELU:
+        a.pro_mode = PRO_LRELU
+    elif pro is not None:
         sc, sh, mode = pro
         assert sc.shape == (x.B, x.C) and sc.stride(1) == 1 and sh.stride() == sc.stride()
         a.pro_scale, a.pro_shift, a.pro_ld, a.pro_mode = ptr(sc), ptr(sh), sc.stride(0), mode
@@ -337,6 +339,13 @@ def fir_nhwc(x: View, kernel2d, up, down, pad, pro=None, want_h=True, want_x=Fal
             pad[0], pad[1], ptr(sc), ptr(sh), ld, mode, oh.ptr if oh else None, oh.ld if oh else 0, ox.ptr if ox else None,
             ox.ld if ox else 0, stream_ptr(), nbytes=4.0 * x.C * (x.npix + x.B * Ho * Wo * (int(want_h) + int(want_x))))
     return oh, ox
+
+
+def minibatch_stddev(x: View, group):
+    """-> [B] tensor: the critic's minibatch-stddev scalar of every sample's group."""
+    out = torch.empty(x.B, device=x.device, dtype=torch.float32)
+    _launch('minibatch_stddev', load().mud_minibatch_stddev, x.ptr, x.B, x.H * x.W, x.C, x.ld, group, ptr(out), stream_ptr())
+    return out
 
 
 def attention_supported(C_):

@@ -560,6 +560,79 @@ def sample_from_model(coef, sd1, sd2, cfg, c1, c2, c3, x_init, zs, noises, retur
 
 
 # --------------------------------------------------------------------------------------
+# the time-conditioned critic, inference forward
+# --------------------------------------------------------------------------------------
+def _lrelu(x):
+    return F.leaky_relu(x, 0.2)
+
+
+def down_conv_block(sd, p, x, t_emb, downsample):
+    """DownConvBlock.forward, backbones/discriminator.py:76-99."""
+    out = _lrelu(x)
+    out = F.conv2d(out, sd[p + '.conv1.0.weight'], sd[p + '.conv1.0.bias'], padding=1)
+    out = out + _lin(sd, p + '.dense_t1', t_emb)[..., None, None]
+    out = _lrelu(out)
+    if downsample:
+        out, x = downsample_2d(out), downsample_2d(x)
+    out = F.conv2d(out, sd[p + '.conv2.0.weight'], sd[p + '.conv2.0.bias'], padding=1)
+    skip = F.conv2d(x, sd[p + '.skip.0.weight'])
+    return (out + skip) / SQRT2
+
+
+def discriminator_large_forward(sd, x, t, x_t, t_emb_dim, stddev_group=4):
+    """Discriminator_large.forward, backbones/discriminator.py:215-263 -> (logit [B], mid_feat)."""
+    temb = timestep_embedding(t, t_emb_dim)
+    temb = _lin(sd, 't_embed.main.2', _lrelu(_lin(sd, 't_embed.main.0', temb)))
+    temb = _lrelu(temb)
+    h = F.conv2d(torch.cat((x, x_t), dim=1), sd['start_conv.weight'], sd['start_conv.bias'])
+    h = down_conv_block(sd, 'conv1', h, temb, True)
+    h = down_conv_block(sd, 'conv2', h, temb, True)
+    mid = down_conv_block(sd, 'conv3', h, temb, True)
+    h = down_conv_block(sd, 'conv4', mid, temb, True)
+    h = down_conv_block(sd, 'conv5', h, temb, True)
+    out = down_conv_block(sd, 'conv6', h, temb, True)
+    b, c, hh, ww = out.shape
+    group = min(b, stddev_group)
+    sdv = out.view(group, -1, 1, c, hh, ww)
+    sdv = torch.sqrt(sdv.var(0, unbiased=False) + 1e-8)
+    sdv = sdv.mean([2, 3, 4], keepdims=True).squeeze(2).repeat(group, 1, hh, ww)
+    out = torch.cat([out, sdv], 1)
+    out = _lrelu(F.conv2d(out, sd['final_conv.weight'], sd['final_conv.bias'], padding=1))
+    out = out.view(b, out.shape[1], -1).sum(2)
+    return _lin(sd, 'end_linear', out).view(-1), mid
+
+
+def discriminator_param_spec(nc, ngf, t_emb_dim):
+    spec = OrderedDict()
+    spec['t_embed.main.0.weight'], spec['t_embed.main.0.bias'] = (t_emb_dim, t_emb_dim), (t_emb_dim,)
+    spec['t_embed.main.2.weight'], spec['t_embed.main.2.bias'] = (t_emb_dim, t_emb_dim), (t_emb_dim,)
+    spec['start_conv.weight'], spec['start_conv.bias'] = (ngf * 2, nc, 1, 1), (ngf * 2,)
+    for i, (ci, co) in enumerate(((2, 4), (4, 8), (8, 8), (8, 8), (8, 8), (8, 8)), start=1):
+        pfx = f'conv{i}'
+        spec[pfx + '.conv1.0.weight'], spec[pfx + '.conv1.0.bias'] = (ngf * co, ngf * ci, 3, 3), (ngf * co,)
+        spec[pfx + '.conv2.0.weight'], spec[pfx + '.conv2.0.bias'] = (ngf * co, ngf * co, 3, 3), (ngf * co,)
+        spec[pfx + '.dense_t1.weight'], spec[pfx + '.dense_t1.bias'] = (ngf * co, t_emb_dim), (ngf * co,)
+        spec[pfx + '.skip.0.weight'] = (ngf * co, ngf * ci, 1, 1)
+    spec['final_conv.weight'], spec['final_conv.bias'] = (ngf * 8, ngf * 8 + 1, 3, 3), (ngf * 8,)
+    spec['end_linear.weight'], spec['end_linear.bias'] = (1, ngf * 8), (1,)
+    return spec
+
+
+def make_discriminator_state_dict(nc, ngf, t_emb_dim, seed=1234):
+    """Same per-name seeding rule as make_state_dict (conv2 is init_scale=0 in the reference: re-drawn at scale 1)."""
+    sd = OrderedDict()
+    for name, shape in discriminator_param_spec(nc, ngf, t_emb_dim).items():
+        g = torch.Generator().manual_seed((zlib.crc32(f'd:{name}'.encode()) + 7919 * seed) % (2 ** 31))
+        if len(shape) >= 2:
+            rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+            bound = math.sqrt(3.0 / ((shape[0] + shape[1]) * rf / 2.0))
+            sd[name] = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * bound
+        else:
+            sd[name] = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
 # metrics (tools/metric_calc.py:40-47; skimage is not installed: restated from the published
 # definitions, "parity unpinned" - the same code scores both the build and the oracle)
 # --------------------------------------------------------------------------------------

@@ -315,6 +315,29 @@ def golden_small_models():
     return out
 
 
+def golden_discriminator():
+    print('critic (Discriminator_large, reference nn.Module with seeded weights)')
+    from backbones.discriminator import Discriminator_large as R_D
+    import torch.nn as nn
+    out = {}
+    for tag, nc, ngf, td, B, H in (('d8', 2, 8, 32, 4, 64), ('d16', 2, 16, 64, 2, 128), ('d8b8', 2, 8, 32, 8, 64)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            d = R_D(nc=nc, ngf=ngf, t_emb_dim=td, act=nn.LeakyReLU(0.2))
+        sd = O.make_discriminator_state_dict(nc, ngf, td, 1234)
+        assert list(d.state_dict().keys()) == list(sd.keys()), 'critic state_dict key order differs'
+        d.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(ngf + B)
+        x, xt = torch.randn(B, 1, H, H, generator=g), torch.randn(B, 1, H, H, generator=g)
+        t = torch.randint(0, 4, (B,), generator=g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            logit, mid = d(x, t, xt)
+        ol, om = O.discriminator_large_forward(sd, x, t, xt, td)
+        check(f'critic.{tag}.logit', ol, logit, 2e-5)
+        check(f'critic.{tag}.mid', om, mid, 2e-5)
+        out.update({f'{tag}.x': x, f'{tag}.xt': xt, f'{tag}.t': t, f'{tag}.logit': logit, f'{tag}.mid': mid})
+    return out
+
+
 def demo_inputs_u8():
     """The reference's own demo data (demo/sample_data/*.jpg), decoded to 8-bit grayscale."""
     from PIL import Image
@@ -364,6 +387,7 @@ def main():
         'fir.npz': t2n(golden_fir()),
         'blocks.npz': t2n(golden_blocks()),
         'small_models.npz': t2n(golden_small_models()),
+        'critic.npz': t2n(golden_discriminator()),
     }
     if not a.skip_full:
         u8, full = golden_full()

@@ -275,6 +275,22 @@ def test_blocks_against_reference_golden():
         assert maxdiff(m(g(gd[f'pyr_{tag}.x'])), gd[f'pyr_{tag}.y']) < 1e-5
 
 
+@pytest.mark.parametrize('tag,nc,ngf,td', [('d8', 2, 8, 32), ('d16', 2, 16, 64), ('d8b8', 2, 8, 32)])
+def test_critic_against_reference_golden(tag, nc, ngf, td):
+    """Discriminator_large(x, t, x_t) -> (logit, mid_feat) on the HIP kernels vs the reference."""
+    import torch.nn as nn
+    from backbones.discriminator import Discriminator_large
+    gd = load_golden('critic.npz')
+    d = Discriminator_large(nc=nc, ngf=ngf, t_emb_dim=td, act=nn.LeakyReLU(0.2))
+    sd = O.make_discriminator_state_dict(nc, ngf, td, 1234)
+    assert list(d.state_dict().keys()) == list(sd.keys())
+    d.load_state_dict(sd)
+    logit, mid = d.to(DEV)(g(gd[f'{tag}.x']), g(gd[f'{tag}.t']), g(gd[f'{tag}.xt']))
+    e1, e2 = maxdiff(logit, gd[f'{tag}.logit']), maxdiff(mid, gd[f'{tag}.mid'])
+    print(f'critic {tag}: logit {e1:.2e} (|logit| ~ {float(gd[f"{tag}.logit"].abs().mean()):.2f}), mid_feat {e2:.2e}')
+    assert e1 <= 1e-3 and e2 <= 1e-4
+
+
 def _build(cfg, seed=1234):
     *_, NCSNpp, NCSNpp_adaptive = _imports()
     g1, g2 = NCSNpp(cfg), NCSNpp_adaptive(cfg)

@@ -111,6 +111,23 @@ def test_small_models_every_step(tag):
             assert (v - g[f'{tag}.step{k}.{nm}']).abs().max() <= 2e-5, (k, nm)
 
 
+CRITIC_CASES = (('d8', 2, 8, 32), ('d16', 2, 16, 64), ('d8b8', 2, 8, 32))
+
+
+@pytest.mark.parametrize('tag,nc,ngf,td', CRITIC_CASES)
+def test_critic_forward_golden(tag, nc, ngf, td):
+    """Discriminator_large inference forward (logit and mid_feat) vs the reference's outputs."""
+    g = load_golden('critic.npz')
+    sd = O.make_discriminator_state_dict(nc, ngf, td, 1234)
+    logit, mid = O.discriminator_large_forward(sd, g[f'{tag}.x'], g[f'{tag}.t'], g[f'{tag}.xt'], td)
+    assert (logit - g[f'{tag}.logit']).abs().max() <= 2e-5 and (mid - g[f'{tag}.mid']).abs().max() <= 2e-5
+
+
+def test_critic_param_count_matches_reference_log():
+    """D = 27,736,705 parameters at nc=2, ngf=64, t_emb_dim=256 (reference error_logs/log_mudiff_T1.13967221.out:116)."""
+    assert sum(int(np.prod(s)) for s in O.discriminator_param_spec(2, 64, 256).values()) == 27736705
+
+
 def test_param_counts_match_reference_log():
     """error_logs/log_mudiff_T1.13967221.out:116 of the reference."""
     cfg = O.default_config()
