@@ -146,10 +146,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       psh_r = *(const f32x4*)(psh + c);
     }
   };
-  auto store_a = [&](int chunk, char* buf) {
+  auto store_a_slots = [&](int chunk, char* buf, int j0, int j1) {
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
+      if (j < j0 || j >= j1) continue;
       f32x4 v = raw[j];
       if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
         v = v * psc_r + psh_r;
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       *(bf16x4*)(buf + loff[j] + 32) = lo;
     }
   };
+  auto store_a = [&](int chunk, char* buf) { store_a_slots(chunk, buf, 0, G::NLOAD); };
 
   // ---- B operand: groups of GS steps are copied global -> LDS by direct-to-LDS loads (no VGPRs, 1 KiB per
   // wave instruction, each wave moves a quarter of the group) into a 2-slot ring, one group ahead of its use.
@@ -241,8 +243,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
             }
           }
         }
+        // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),
+        // so the conversion VALU work interleaves with matrix work instead of forming one long MFMA-free stretch
+        if (more && G::NG > 1 && st >= G::GS) {
+          constexpr int SPAN = G::STEPS - G::GS;                   // steps available for staging
+          const int j0 = ((st - G::GS) * G::NLOAD) / SPAN, j1 = ((st - G::GS + 1) * G::NLOAD) / SPAN;
+          store_a_slots(kc + 1, nxt, j0, j1);
+        }
       }
-      if (g == (G::NG > 1 ? 1 : 0) && more) store_a(kc + 1, nxt);   // chunk k+1's LDS image, after its raw loads had a group to land
+      if (G::NG == 1 && more) store_a(kc + 1, nxt);
       __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
     }
   }
