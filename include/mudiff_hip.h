@@ -98,7 +98,10 @@ typedef struct mud_conv_args {
   const float* bias;                             /* [Cout] or NULL                                   */
   const float* bias2; int bias2_ld;              /* [B,Cout] or NULL  (Dense_0(act(temb)))           */
   const float* res; int ldr;                     /* residual view [B,Ho,Wo,Cout] or NULL             */
-  float out_scale; int act;                      /* out = act((acc+bias+bias2+res)*out_scale)        */
+  float out_scale; int act;                      /* v = act((acc+bias+bias2+res)*out_scale)          */
+  const float* emul; int ld_emul;                /* optional: v *= emul[pixel, co]                   */
+  const float* egate; int ld_egate;              /* optional gated mix (G2 feature fusion, ...feat.py */
+  const float* eother; int ld_eother;            /* :779-788): v = egate*v + (1-egate)*eother         */
   float* out; int Cout, ldo;                     /* output view [B,Ho,Wo,Cout]                       */
   int sub2;                                      /* mud_conv2d_mfma, ks 3 only: compute the stride-1  */
                                                  /* pad-1 result and keep only odd (y,x) positions as */

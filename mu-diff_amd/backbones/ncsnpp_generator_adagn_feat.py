@@ -194,12 +194,14 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         tail_conv = mods[self._plan[-1]['idx']]
         p['tail'] = layerspp.ConvParam(tail_conv)
         if self.ADAPTIVE:
-            gates = [self.feat_att1_c12, self.feat_att2_c12, self.feat_att1_c23, self.feat_att2_c23, self.feat_att1_c31,
-                     self.feat_att2_c31]
-            wg = torch.cat([g.weight for g in gates], 0).contiguous()          # [6nf, 3nf, 3, 3]
-            p['gates_w'] = ops.pack_conv_weight(wg) if layerspp.use_mfma(wg.shape[1], wg.shape[0]) else ops.direct_weight(wg)
-            p['gates_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
-            p['gates_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
+            # the six sigmoid gate convs share their input (reference :769-776): two convs of 3*nf output channels -
+            # the att1 gates (multiplied by the feature they gate in the epilogue) and the att2 gates
+            for key, gates in (('g1', (self.feat_att1_c12, self.feat_att1_c23, self.feat_att1_c31)),
+                               ('g2', (self.feat_att2_c12, self.feat_att2_c23, self.feat_att2_c31))):
+                wg = torch.cat([g.weight for g in gates], 0).contiguous()          # [3nf, 3nf, 3, 3]
+                p[key + '_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
+                p[key + '_w'] = ops.pack_conv_weight(wg) if p[key + '_mfma'] else ops.direct_weight(wg)
+                p[key + '_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
             p['fw'] = [layerspp.ConvParam(c) for c in (self.feat_weight_c1, self.feat_weight_c2, self.feat_weight_c3)]
             ada = [mods[e['idx']] for e in self._plan if e['kind'] == 'ada']
             p['ada_w'] = torch.cat([m.group_norm.style.weight for m in ada], 0).contiguous()
@@ -386,10 +388,11 @@ class NCSNpp_adaptive(_NCSNppBase):
             cat = View.empty(B, H, W, 3 * nf, dev)
             for j, (e, c) in enumerate(zip(e_ada, (cond1, cond2, cond3))):
                 mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf), arena=arena)
-            # six sigmoid gate convs share their input: one conv with 6*nf output channels (reference :769-776)
-            gates = ops.conv(cat, p['gates_w'], 3, 6 * nf, mfma=p['gates_mfma'], bias=p['gates_b'], act=ACT_SIGMOID)
-            for j, (a, b_) in enumerate(((0, 1), (1, 2), (2, 0))):      # (c1,c2), (c2,c3), (c3,c1)  (reference :778-788)
-                g1, g2 = gates.slice(2 * j * nf, nf), gates.slice((2 * j + 1) * nf, nf)
-                att = p['fw'][j](ops.mul(g1, cat.slice(a * nf, nf)))
-                ops.gate_mix(g2, att, cat.slice(b_ * nf, nf), hs0.slice((j + 1) * nf, nf))
+            # att1 gates already multiplied by the feature they gate: sigmoid(conv(cat)) * cat (pairs gate c1, c2, c3 in
+            # this order, reference :778,783,787); att2 gates: plain sigmoid
+            gated = ops.conv(cat, p['g1_w'], 3, 3 * nf, mfma=p['g1_mfma'], bias=p['g1_b'], act=ACT_SIGMOID, emul=cat)
+            g2all = ops.conv(cat, p['g2_w'], 3, 3 * nf, mfma=p['g2_mfma'], bias=p['g2_b'], act=ACT_SIGMOID)
+            for j, b_ in enumerate((1, 2, 0)):      # fused_ij = g2 * conv(g1 * c_i) + (1 - g2) * c_j   (reference :779-788)
+                p['fw'][j](gated.slice(j * nf, nf), gate=(g2all.slice(j * nf, nf), cat.slice(b_ * nf, nf)),
+                           out=hs0.slice((j + 1) * nf, nf))
             return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)

@@ -74,7 +74,13 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
       if (a.bias) v += a.bias[co + j];
       if (a.bias2) v += a.bias2[(int64_t)b * a.bias2_ld + co + j];
       if (a.res) v += a.res[opix * a.ldr + co + j];
-      acc[j] = mud_act(v * a.out_scale, a.act);
+      v = mud_act(v * a.out_scale, a.act);
+      if (a.emul) v *= a.emul[opix * a.ld_emul + co + j];
+      if (a.egate) {
+        const float gt = a.egate[opix * a.ld_egate + co + j];
+        v = gt * v + (1.0f - gt) * a.eother[opix * a.ld_eother + co + j];
+      }
+      acc[j] = v;
     }
     float* op = a.out + opix * a.ldo + co;
     if (VO == 4) *(f32x4*)op = *(f32x4*)acc;
@@ -193,7 +199,7 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   const bool vo4 = a.Cout % 4 == 0 && a.ldo % 4 == 0 && mud_aligned16(a.out) && mud_aligned16(a.w) && (a.w_bstride % 16 == 0);
   const bool vi4 = a.Cin % 4 == 0 && a.ldx % 4 == 0 && mud_aligned16(a.x);
   const int co_groups = vo4 ? a.Cout / 4 : a.Cout;
-  if (a.Cin == 1 && a.ks == 3 && a.stride == 1 && a.pad == 1 && vo4 && co_groups <= 256 && a.pro_mode == MUD_PRO_NONE && a.w_bstride == 0 &&
+  if (a.Cin == 1 && a.ks == 3 && a.stride == 1 && a.pad == 1 && vo4 && !a.emul && !a.egate && co_groups <= 256 && a.pro_mode == MUD_PRO_NONE && a.w_bstride == 0 &&
       (!a.res || (a.ldr % 4 == 0 && mud_aligned16(a.res))) && (!a.bias || mud_aligned16(a.bias)) &&
       (!a.bias2 || (a.bias2_ld % 4 == 0 && mud_aligned16(a.bias2)))) {
     MUD_REQUIRE(a.B <= 65535 && (!a.stats || a.stats_ld >= a.Cout), "mud_conv2d_direct: bad batch / stats view");

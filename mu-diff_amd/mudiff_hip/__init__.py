@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ('bias2', C.c_void_p), ('bias2_ld', C.c_int),
         ('res', C.c_void_p), ('ldr', C.c_int),
         ('out_scale', C.c_float), ('act', C.c_int),
+        ('emul', C.c_void_p), ('ld_emul', C.c_int), ('egate', C.c_void_p), ('ld_egate', C.c_int), ('eother', C.c_void_p), ('ld_eother', C.c_int),
         ('out', C.c_void_p), ('Cout', C.c_int), ('ldo', C.c_int),
         ('sub2', C.c_int),
         ('stats', C.c_void_p), ('stats_ld', C.c_int),
