@@ -210,6 +210,19 @@ def main():
                                 'vs_fp32_peak_157.3': round(ach / PEAK_FP32_TFLOPS, 3),
                                 'share_of_gpu_time': round(k['ms'] / sum(v['ms'] for v in prof.values()), 3)}
             line['kernel_time_ms_per_batch'] = {n: round(v['ms'], 3) for n, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
+    if rank == 0 and world == 1 and B != 1 and not a.no_roofline:
+        # latency case of BASELINE config 2 read literally (batch = 1): one slice at a time through its own hipGraph
+        s1 = S.GraphSampler(coef, g1, g2, cfg, 1, H, H, dev)
+        x1 = torch.randn(1, 1, H, H, device=dev)
+        for _ in range(2):
+            s1.sample(c1[:1], c2[:1], c3[:1], x1, cfg.num_timesteps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(6):
+            s1.sample(c1[:1], c2[:1], c3[:1], x1, cfg.num_timesteps)
+        torch.cuda.synchronize()
+        line['batch1'] = {'slices_per_s': round(6 / (time.perf_counter() - t1), 2), 'note': 'same path, 1 slice per step (latency case)'}
+        del s1
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log('timing the CPU oracle on one slice ...')
         line['cpu_baseline'] = cpu_baseline(cfg)
