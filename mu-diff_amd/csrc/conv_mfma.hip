@@ -60,7 +60,7 @@ struct CmGeo {
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
   static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
   static constexpr int LDS_BYTES = (A_BYTES + 2 * GB) > EP_BYTES ? (A_BYTES + 2 * GB) : EP_BYTES;
-  static_assert(NT % Q == 0 && PIECES % (WM * WN) == 0, "staging / DMA split");
+  static_assert(NT % Q == 0, "staging split");
 };
 
 
@@ -181,8 +181,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
     if (gg >= total_groups) return;             // wave-uniform
     char* dst = bring + (gg & 1) * G::GB;
 #pragma unroll
-    for (int j = 0; j < G::PIECES / (WM * WN); ++j) {
+    for (int j = 0; j < (G::PIECES + WM * WN - 1) / (WM * WN); ++j) {
       const int piece = wave + WM * WN * j;     // wave-uniform 1 KiB piece of the group image [WN tiles][GS steps][hi|lo][2 KiB]
+      if (piece >= G::PIECES) break;
       const int t64 = piece / (G::GB1 / 1024), within = piece % (G::GB1 / 1024);
       const char* src = wb + t64 * tile_bytes + (int64_t)gg * G::GB1 + within * 1024 + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -826,7 +827,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   const int64_t ntiles = mud_cdiv(a.Cout, CM_BN);
   static const int force_mt = getenv("MUD_CONV_MT") ? atoi(getenv("MUD_CONV_MT")) : 0;   // tuning knob
   if (force_mt) {
-    if (a.ks == 3) return (force_mt == 8 && ntiles % 2 == 0) ? cm_launch<3, 2, 4, 2>(a, s) : force_mt == 1 ? cm_launch<3, 1>(a, s) : cm_launch<3, 2>(a, s);
+    if (a.ks == 3) return (force_mt == 8 && ntiles % 2 == 0) ? cm_launch<3, 2, 4, 2>(a, s) : force_mt == 16 ? cm_launch<3, 2, 8, 1>(a, s) : force_mt == 1 ? cm_launch<3, 1>(a, s) : cm_launch<3, 2>(a, s);
     return force_mt == 4 ? cm_launch<1, 4>(a, s) : force_mt == 2 ? cm_launch<1, 2>(a, s) : cm_launch<1, 1>(a, s);
   }
   // Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
@@ -837,6 +838,11 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
     // of 64-channel tiles and still fills the chip
     const int64_t blocks8 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * (ntiles / 2) * a.B;
     if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) return cm_launch<3, 2, 4, 2>(a, s);
+    // other layers (64 or an odd number of 64-channel tiles): 8 waves stacked along the rows (16 x 32 px x 64 channels):
+    // less halo per staged pixel and the weight ring is shared by twice as many waves (+4-7 % measured)
+    const int64_t blocks16 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 16) * ntiles * a.B;
+    static const bool no16 = getenv("MUD_CONV_NO16") != nullptr;   // A/B knob
+    if (!no16 && a.H >= 16 && blocks16 >= 256) return cm_launch<3, 2, 8, 1>(a, s);
     const int64_t blocks2 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * ntiles * a.B;
     if (blocks2 >= 512 && a.H >= 8) return cm_launch<3, 2>(a, s);
     return cm_launch<3, 1>(a, s);

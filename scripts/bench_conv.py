@@ -9,7 +9,7 @@ shapes = [ s for s in [  # H, Cin, Cout, ks
     (128, 64, 128, 3), (128, 128, 128, 3), (128, 384, 128, 3), (128, 256, 128, 3), (128, 192, 128, 3),
     (64, 128, 256, 3), (64, 256, 256, 3), (64, 512, 256, 3), (64, 384, 256, 3),
     (256, 256, 64, 1), (128, 64, 128, 1), (64, 128, 256, 1), (64, 256, 768, 1), (64, 256, 256, 1), (64, 512, 256, 1), (128, 384, 128, 1),
-] if (len(sys.argv) < 3 or s[2] % 128 == 0) ]
+] if (len(sys.argv) < 3 or (sys.argv[2] == "only128" and s[2] % 128 == 0) or (sys.argv[2] == "only64" and s[2] == 64 and s[3] == 3)) ]
 dev = 'cuda:0'
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
