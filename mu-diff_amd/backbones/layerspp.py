@@ -1,3 +1,4 @@
+import os
 """NCSN++ building blocks with AdaGN (reference backbones/layerspp.py), MI355X-native.
 
 Every block keeps the reference's class name, constructor signature, parameter names/shapes and
@@ -232,6 +233,11 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         d = dict(c0=ConvParam(self.Conv_0), c1=ConvParam(self.Conv_1))
         if hasattr(self, 'Conv_2'):
             d['c2'] = ConvParam(self.Conv_2)
+            if self.up:
+                # FIR up-sampling and the 1x1 skip conv are both linear and commute: run the conv at LOW resolution (4x
+                # fewer pixels) without its bias, up-sample the result, and add the bias (a constant) in Conv_1's epilogue
+                d['c2'].bias = None
+                d['c1'].bias = (self.Conv_1.bias.detach() + self.Conv_2.bias.detach()).contiguous()
         return d
 
     def run(self, x: View, style0, style1, tbias, out: View = None, arena=None):
@@ -242,15 +248,20 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
             raise NotImplementedError('dropout > 0 in training mode is not part of the inference path')
         p = self.prepared()
         sc0, sh0 = self.GroupNorm_0.scale_shift(x, style0)
-        if self.up or self.down:
-            kk, up, down, pad = up_or_down_sampling.fir_params('up' if self.up else 'down', self.fir_kernel)
+        if self.up:
+            kk, up, down, pad = up_or_down_sampling.fir_params('up', self.fir_kernel)
+            h_in, _ = ops.fir_nhwc(x, kk, up, down, pad, pro=(sc0, sh0, PRO_AFFINE_SILU), want_h=True, want_x=False)
+            x_skip, _ = ops.fir_nhwc(p['c2'](x), kk, up, down, pad)          # = Conv_2(FIR(x)) minus its bias (see _prepare)
+            h = p['c0'](h_in, bias2=tbias, arena=arena)
+        elif self.down:
+            kk, up, down, pad = up_or_down_sampling.fir_params('down', self.fir_kernel)
             h_in, x_skip = ops.fir_nhwc(x, kk, up, down, pad, pro=(sc0, sh0, PRO_AFFINE_SILU), want_h=True, want_x=True)
             h = p['c0'](h_in, bias2=tbias, arena=arena)
         else:
             x_skip = x
             h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena)
         sc1, sh1 = self.GroupNorm_1.scale_shift(h, style1)
-        if 'c2' in p:
+        if 'c2' in p and not self.up:
             x_skip = p['c2'](x_skip)
         return p['c1'](h, pro=(sc1, sh1, PRO_AFFINE_SILU), res=x_skip, out_scale=INV_SQRT2 if self.skip_rescale else 1.0, out=out)
 
