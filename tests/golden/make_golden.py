@@ -375,12 +375,38 @@ def golden_full():
     return u8, out
 
 
+CFG5 = dict(ch_mult=[1, 1, 2, 2, 4], num_timesteps=8, attn_resolutions=(16,))   # BASELINE config 5
+
+
+def golden_cfg5():
+    print('config 5: 256x256, ch_mult 1-1-2-2-4, attention at 16x16 in the down/up paths, 8 steps (takes a few minutes)')
+    cfg = O.default_config(**CFG5)
+    u8 = np.load(os.path.join(HERE, 'demo_inputs_u8.npz')) if os.path.exists(os.path.join(HERE, 'demo_inputs_u8.npz')) else demo_inputs_u8()
+    conds = [preprocess_demo(u8[n]) for n in ('flair', 't2', 't1')]
+    x_init, zs, noises, steps, o_steps = run_sampler(cfg, 1234, 42, conds, 1)
+    out = {}
+    for k, (r, o) in enumerate(zip(steps, o_steps)):
+        for nm, a, b in zip(('x01', 'x02', 'xnew'), o, r):
+            check(f'cfg5.step{k}.{nm}', a, b, 5e-5)
+            if nm == 'xnew' or k in (0, len(steps) - 1):       # every x_new, both predictions at the first and last step
+                out[f'step{k}.{nm}'] = b.numpy().astype(np.float32)
+    print(f'    cfg5: |x01| std {float(steps[0][0].std()):.3f}, final range [{float(steps[-1][2].min()):.3f},{float(steps[-1][2].max()):.3f}]')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true', help='validate the oracle only, write nothing')
     ap.add_argument('--skip-full', action='store_true')
+    ap.add_argument('--only-cfg5', action='store_true', help='(re)generate full_cfg5.npz alone')
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.only_cfg5:
+        d = golden_cfg5()
+        if not a.check:
+            np.savez_compressed(os.path.join(HERE, 'full_cfg5.npz'), **d)
+            print('wrote full_cfg5.npz', f'{os.path.getsize(os.path.join(HERE, "full_cfg5.npz")) / 1e6:.2f} MB')
+        return
     files = {
         'kat_schedules.npz': t2n(golden_schedules()),
         'elementwise.npz': t2n(golden_elementwise()),
@@ -393,6 +419,7 @@ def main():
         u8, full = golden_full()
         files['demo_inputs_u8.npz'] = u8
         files['full_cfg2.npz'] = full
+        files['full_cfg5.npz'] = golden_cfg5()
     worst = max(REPORT, key=lambda r: r[1])
     print(f'{len(REPORT)} comparisons, worst: {worst[0]} {worst[1]:.3e}')
     if not a.check:

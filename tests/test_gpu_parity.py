@@ -344,6 +344,24 @@ def test_config2_full_size_every_step_vs_reference():
     assert abs(dp) <= 0.05 and abs(ds) <= 0.001
 
 
+def test_config5_isles_shaped_8_steps_vs_reference():
+    """BASELINE config 5: 256x256, 8 timesteps, ch_mult 1-1-2-2-4 so that attn_resolutions=16
+    fires in the down and up paths (N=256 keys, C=256) as well as in the middle; golden made by the reference itself."""
+    ops, S, *_ = _imports()
+    gd = load_golden('full_cfg5.npz')
+    cfg = O.default_config(ch_mult=[1, 1, 2, 2, 4], num_timesteps=8, attn_resolutions=(16,))
+    g1, g2 = _build(cfg)
+    conds = [g(c) for c in demo_conds()]
+    x_init, zs, noises = sampler_inputs(cfg, 1)
+    coef = S.Posterior_Coefficients(cfg, DEV)
+    x, steps = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], 8, g(x_init), None, cfg,
+                                   zs=[g(z) for z in zs], noises=[g(n) for n in noises], return_steps=True)
+    for k, st in enumerate(steps):
+        errs = {nm: maxdiff(v, gd[f'step{k}.{nm}']) for nm, v in zip(('x01', 'x02', 'xnew'), st) if f'step{k}.{nm}' in gd}
+        print(f'cfg5 step {k}: max-abs ' + ' '.join(f'{nm} {e:.2e}' for nm, e in errs.items()))
+        assert max(errs.values()) <= 1e-3
+
+
 @pytest.mark.parametrize('H,W,B,kw', [(40, 40, 3, dict(num_channels_dae=32, ch_mult=[1, 2, 4], attn_resolutions=(10,))),
                                        (24, 56, 2, dict(num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(), num_res_blocks=1)),
                                        (240, 240, 1, dict(num_channels_dae=32, ch_mult=[1, 2, 4], attn_resolutions=(60,), num_res_blocks=1))])

@@ -148,6 +148,21 @@ def test_config1_single_g1_forward_full_size():
     assert (y - g['step0.x01']).abs().max() <= 5e-5
 
 
+def test_config5_first_step_full_size():
+    """BASELINE config 5 (8 steps, ch_mult 1-1-2-2-4, attention at 16x16 in the down/up paths): G1 and G2 at the first
+    reverse step (t=7) against the reference's own outputs."""
+    g = load_golden('full_cfg5.npz')
+    cfg = O.default_config(ch_mult=[1, 1, 2, 2, 4], num_timesteps=8, attn_resolutions=(16,))
+    sd1, sd2 = O.make_state_dict(cfg, 'g1', 1234), O.make_state_dict(cfg, 'g2', 1234)
+    conds = demo_conds()
+    x_init, zs, _ = sampler_inputs(cfg, 1)
+    t = torch.full((1,), 7, dtype=torch.int64)
+    y1 = O.g1_forward(sd1, cfg, x_init, *conds, t, zs[0])
+    y2 = O.g2_forward(sd2, cfg, x_init, *conds, t, zs[0], y1[:, [0], :])
+    assert (y1 - g['step0.x01']).abs().max() <= 5e-5
+    assert (y2 - g['step0.x02']).abs().max() <= 5e-5
+
+
 def test_metrics_sanity():
     rng = np.random.default_rng(0)
     a = rng.random((64, 64))
