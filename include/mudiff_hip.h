@@ -162,6 +162,12 @@ int mud_mul(const float* a, int lda, const float* b, int ldb, float* out, int ld
 int mud_gate_mix(const float* g, int ldg, const float* att, int lda, const float* other, int ldb,
                  float* out, int ldo, int B, int64_t hw, int C, double* stats, int stats_ld, void* stream);
 
+/* ---- rows f1 / f3: bilinear resize of planes [P,H,W] -> [P,Ho,Wo] with torch F.interpolate(mode='bilinear',
+ *      align_corners=False) semantics (engine/test_volume.py:274 slice -> image_size; engine/train.py:959 uncertainty map),
+ *      and out = clamp(x*scale + shift, lo, hi) (the [-1,1] -> [0,1] mapping, engine/test_volume.py:281). */
+int mud_resize_bilinear(const float* in, int64_t planes, int H, int W, int Ho, int Wo, float* out, void* stream);
+int mud_affine_clamp(const float* x, int64_t n, float scale, float shift, float lo, float hi, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

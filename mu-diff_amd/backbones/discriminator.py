@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from mudiff_hip import ops
-from mudiff_hip.ops import ACT_LRELU, ACT_NONE, INV_SQRT2, PRO_LRELU, View
+from mudiff_hip.ops import ACT_LRELU, ACT_NONE, ACT_SIGMOID, INV_SQRT2, PRO_LRELU, View
 
 from . import dense_layer, layers, layerspp, up_or_down_sampling
 
@@ -162,3 +162,19 @@ class Discriminator_large(_DiscriminatorBase):
             h = self.conv5.run(h, t_embed)
             h = self.conv6.run(h, t_embed)
             return self._head(h, p), mid.to_nchw()
+
+
+def uncertainty_map(att_conv, mid_feat, size):
+    """Uncertainty / attention map of the critic's mid feature (reference engine/train.py:957-959, `att_conv =
+    conv2d(64*8, 1, 1, padding=0)` at :466): sigmoid(att_conv(mid_feat)) up-sampled bilinearly (align_corners=False)
+    to `size` = the image's (H, W).  -> [B,1,H,W].  The 1x1 conv + sigmoid run as one MFMA-conv launch, the resize as one
+    HIP kernel."""
+    ops.require_gpu(mid_feat)
+    key = (att_conv.weight._version, att_conv.weight.data_ptr(), None if att_conv.bias is None else att_conv.bias._version)
+    cache = att_conv.__dict__.get('_mud_param')
+    if cache is None or cache[0] != key:
+        cache = (key, layerspp.ConvParam(att_conv))
+        att_conv.__dict__['_mud_param'] = cache
+    with torch.no_grad(), torch.autocast('cuda', enabled=False):
+        m = cache[1](View.from_nchw(mid_feat.detach().float()), act=ACT_SIGMOID)        # [B,h,w,1]
+        return ops.resize_bilinear(m.to_nchw(), size)

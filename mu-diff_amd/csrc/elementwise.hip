@@ -356,3 +356,67 @@ extern "C" int mud_minibatch_stddev(const float* x, int B, int64_t hw, int C, in
   MUD_CHECK_LAUNCH("mud_minibatch_stddev");
   return MUD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear resize of planes, torch `F.interpolate(mode='bilinear', align_corners=False)` semantics
+// (the reference's calls: engine/test_volume.py:274 slices -> image_size, engine/train.py:959
+// uncertainty map -> image size).  Half-pixel centres: src = (dst + 0.5) * in/out - 0.5 clamped at 0;
+// neighbours i0 = min(int(src), in-1), i1 = i0 + (i0 < in-1); weight of i1 = clamp(src - i0, 0, 1).
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ __forceinline__ void mud_bilinear_src(int dst, float scale, int in, int& i0, int& i1, float& w1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = min((int)src, in - 1);
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void k_resize_bilinear(const float* __restrict__ in, int64_t planes, int H, int W, int Ho, int Wo,
+                                                         float sy, float sx, float* __restrict__ out) {
+  const int64_t total = planes * Ho * Wo;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wo);
+    const int64_t r = idx / Wo;
+    const int oy = (int)(r % Ho);
+    const float* ip = in + (r / Ho) * H * W;
+    int y0, y1, x0, x1;
+    float wy, wx;
+    mud_bilinear_src(oy, sy, H, y0, y1, wy);
+    mud_bilinear_src(ox, sx, W, x0, x1, wx);
+    const float top = (1.f - wx) * ip[(int64_t)y0 * W + x0] + wx * ip[(int64_t)y0 * W + x1];
+    const float bot = (1.f - wx) * ip[(int64_t)y1 * W + x0] + wx * ip[(int64_t)y1 * W + x1];
+    out[idx] = (1.f - wy) * top + wy * bot;
+  }
+}
+
+extern "C" int mud_resize_bilinear(const float* in, int64_t planes, int H, int W, int Ho, int Wo, float* out, void* stream) {
+  MUD_REQUIRE(planes >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "mud_resize_bilinear: bad sizes");
+  if (planes == 0) return MUD_OK;
+  MUD_REQUIRE(in && out, "mud_resize_bilinear: null pointer");
+  int64_t blocks = mud_cdiv(planes * Ho * Wo, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(k_resize_bilinear, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, planes, H, W, Ho, Wo,
+                     (float)H / (float)Ho, (float)W / (float)Wo, out);
+  MUD_CHECK_LAUNCH("mud_resize_bilinear");
+  return MUD_OK;
+}
+
+// out = clamp(x * scale + shift, lo, hi): the sampler's [-1,1] -> [0,1] image mapping (engine/test_volume.py:281,
+// engine/test.py to_range_0_1) with scale = shift = 0.5, lo = 0, hi = 1.
+__global__ __launch_bounds__(256) void k_affine_clamp(const float* __restrict__ x, int64_t n, float scale, float shift, float lo, float hi,
+                                                      float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = fminf(fmaxf(x[i] * scale + shift, lo), hi);
+}
+
+extern "C" int mud_affine_clamp(const float* x, int64_t n, float scale, float shift, float lo, float hi, float* out, void* stream) {
+  MUD_REQUIRE(n >= 0, "mud_affine_clamp: bad size");
+  if (n == 0) return MUD_OK;
+  MUD_REQUIRE(x && out, "mud_affine_clamp: null pointer");
+  int64_t blocks = mud_cdiv(n, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(k_affine_clamp, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale, shift, lo, hi, out);
+  MUD_CHECK_LAUNCH("mud_affine_clamp");
+  return MUD_OK;
+}

@@ -388,4 +388,30 @@ def gate_mix(g: View, att: View, other: View, out: View):
     return out
 
 
+def resize_bilinear(x, size):
+    """x [..., H, W] planes -> [..., Ho, Wo]; `F.interpolate(x, size, mode='bilinear', align_corners=False)` semantics
+    (reference engine/test_volume.py:274, engine/train.py:959)."""
+    require_gpu(x)
+    H, W = x.shape[-2:]
+    Ho, Wo = int(size[0]), int(size[1])
+    xin = _f32(x.float().contiguous())
+    out = torch.empty(*x.shape[:-2], Ho, Wo, device=x.device, dtype=torch.float32)
+    _launch('resize_bilinear', load().mud_resize_bilinear, ptr(xin), xin.numel() // (H * W), H, W, Ho, Wo, ptr(out), stream_ptr())
+    return out
+
+
+def affine_clamp(x, scale, shift, lo, hi):
+    """clamp(x*scale + shift, lo, hi) elementwise (fp32)."""
+    require_gpu(x)
+    xin = _f32(x.float().contiguous())
+    out = torch.empty_like(xin)
+    _launch('affine_clamp', load().mud_affine_clamp, ptr(xin), xin.numel(), float(scale), float(shift), float(lo), float(hi), ptr(out), stream_ptr())
+    return out
+
+
+def to_range_0_1(x):
+    """[-1,1] -> [0,1] with clipping: ((x + 1) / 2).clamp(0, 1) (reference engine/test_volume.py:281)."""
+    return affine_clamp(x, 0.5, 0.5, 0.0, 1.0)
+
+
 INV_SQRT2 = 1.0 / math.sqrt(2.0)

@@ -655,3 +655,77 @@ def ssim(gt, pred, data_range=1.0, win=7, k1=0.01, k2=0.03):
     s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
     pad = (win - 1) // 2
     return float(s[pad:-pad, pad:-pad].mean())
+
+
+# --------------------------------------------------------------------------------------
+# row f1: uncertainty map of the critic's mid feature (engine/train.py:466,957-962)
+# --------------------------------------------------------------------------------------
+def resize_bilinear(x, size):
+    """`F.interpolate(x, size=size, mode='bilinear', align_corners=False)` - the call the reference makes at
+    engine/train.py:959 and engine/test_volume.py:274.  Half-pixel centres: src = (dst + 0.5) * in/out - 0.5, clamped
+    at 0; the two neighbours are floor(src) and min(floor(src)+1, in-1)."""
+    return F.interpolate(x, size=tuple(size), mode='bilinear', align_corners=False)
+
+
+def uncertainty_map(mid_feat, att_w, att_b, size):
+    """sigmoid(conv1x1(mid_feat)) up-sampled bilinearly to the image size (engine/train.py:957-959; `att_conv` is
+    `conv2d(64*8, 1, 1, padding=0)`, :466)."""
+    return resize_bilinear(torch.sigmoid(F.conv2d(mid_feat, att_w, att_b)), size)
+
+
+# --------------------------------------------------------------------------------------
+# row f3: volume pipeline (engine/test_volume.py:135-191, 236-300)
+# --------------------------------------------------------------------------------------
+def robust_minmax_to_minus1_1(vol, mask=None, pmin=1.0, pmax=99.0):
+    """engine/test_volume.py:135-157: percentiles [pmin, pmax] over the non-zero (or masked, non-NaN) voxels, linear map to
+    [0,1] with clipping, then to [-1,1].  Degenerate inputs (no voxels / flat) give zeros."""
+    data = np.asarray(vol).astype(np.float32, copy=False)
+    sel = (data != 0) if mask is None else (np.asarray(mask).astype(bool) & ~np.isnan(data))
+    if not sel.any():
+        return np.zeros_like(data, dtype=np.float32)
+    vals = data[sel]
+    lo, hi = np.percentile(vals, pmin), np.percentile(vals, pmax)
+    if not (np.isfinite(lo) and np.isfinite(hi)) or hi <= lo:
+        lo, hi = float(vals.min()), float(vals.max())
+        if hi <= lo:
+            return np.zeros_like(data, dtype=np.float32)
+    return np.clip((data - lo) / (hi - lo), 0.0, 1.0) * 2.0 - 1.0
+
+
+def extract_center_slices(volume, half_range):
+    """engine/test_volume.py:159-168: axial slices [c - half_range, c + half_range] around c = Z // 2, clipped to the volume."""
+    z = volume.shape[2]
+    c = z // 2
+    s0, s1 = max(0, c - half_range), min(z - 1, c + half_range)
+    return [volume[:, :, k] for k in range(s0, s1 + 1)], s0, s1
+
+
+def reconstruct_volume_from_slices(slices, shape, s0, s1):
+    """engine/test_volume.py:170-181: predicted slices go back to planes s0.., everything else stays zero."""
+    vol = np.zeros(shape, dtype=np.float32)
+    for i, sl in enumerate(slices):
+        k = s0 + i
+        if k <= s1 and k < shape[2]:
+            vol[:, :, k] = np.asarray(sl, dtype=np.float32)
+    return vol
+
+
+def predict_volume(coef, sd1, sd2, cfg, volumes, half_range, x_inits, zs, noises):
+    """engine/test_volume.py:262-291 restated per slice (B=1, like the reference) with the Gaussian draws injected:
+    `volumes` are the three RAW condition volumes [X,Y,Z] in the order the target modality prescribes;
+    x_inits[i] is slice i's starting noise [1,1,S,S], zs[i] / noises[i] its per-step draws.  Returns the [0,1] slices
+    at the model's image size (the reference writes them straight back into the volume, so X,Y must equal S there)."""
+    S = cfg.image_size
+    per_mod = [extract_center_slices(robust_minmax_to_minus1_1(v), half_range) for v in volumes]
+    n = len(per_mod[0][0])
+    out = []
+    for i in range(n):
+        conds = []
+        for sl, _, _ in per_mod:
+            t = torch.from_numpy(np.asarray(sl[i], dtype=np.float32))[None, None]
+            if tuple(t.shape[-2:]) != (S, S):
+                t = resize_bilinear(t, (S, S))
+            conds.append(t)
+        fake = sample_from_model(coef, sd1, sd2, cfg, conds[0], conds[1], conds[2], x_inits[i], zs[i], noises[i])
+        out.append(((fake + 1.0) / 2.0).clamp(0.0, 1.0).numpy().squeeze())
+    return out, per_mod[0][1], per_mod[0][2]

@@ -394,13 +394,88 @@ def golden_cfg5():
     return out
 
 
+def ref_volume_namespace():
+    """exec engine/test_volume.py:135-181 (robust_minmax_to_minus1_1, extract_center_slices, reconstruct_volume_from_slices):
+    the module itself cannot be imported (nibabel is not installed), these three functions are pure numpy."""
+    import typing
+    ns = {'np': np, 'torch': torch, 'Optional': typing.Optional, 'List': typing.List, 'Tuple': typing.Tuple, 'Dict': typing.Dict}
+    lines = open(os.path.join(REF, 'engine/test_volume.py')).read().split('\n')
+    exec('\n'.join(lines[134:181]), ns)
+    return ns
+
+
+def golden_volume():
+    print('volume pipeline pieces (engine/test_volume.py) + uncertainty map (engine/train.py:957-959)')
+    import torch.nn.functional as F
+    V = ref_volume_namespace()
+    rng = np.random.default_rng(2024)
+    out = {}
+    # three "modalities" of one synthetic head: smooth blobs inside an ellipsoid, exact zeros outside, a few hot voxels
+    X, Y, Z = 20, 24, 11
+    xx, yy, zz = np.meshgrid(np.linspace(-1, 1, X), np.linspace(-1, 1, Y), np.linspace(-1, 1, Z), indexing='ij')
+    inside = (xx ** 2 + yy ** 2 / 0.8 + zz ** 2 / 1.2) < 0.8
+    for m in range(3):
+        v = (200 + 80 * np.sin(3 * xx + m) * np.cos(2 * yy - m) + 30 * rng.standard_normal((X, Y, Z))) * inside
+        v[rng.integers(0, X, 5), rng.integers(0, Y, 5), rng.integers(0, Z, 5)] = 4000.0      # outliers the percentiles must clip
+        v = v.astype(np.float64)                                                            # nibabel's get_fdata() dtype
+        out[f'vol{m}'] = v
+        r = V['robust_minmax_to_minus1_1'](v)
+        check(f'volume.norm{m}', torch.from_numpy(O.robust_minmax_to_minus1_1(v)), torch.from_numpy(r), 0)
+        out[f'norm{m}'] = r
+    mask = inside & (yy > -0.2)
+    vn = out['vol0'].copy(); vn[3, 3, 3] = np.nan
+    r = V['robust_minmax_to_minus1_1'](vn, mask=mask, pmin=5.0, pmax=90.0)
+    o = O.robust_minmax_to_minus1_1(vn, mask=mask, pmin=5.0, pmax=90.0)
+    assert np.array_equal(r, o, equal_nan=True)
+    out['mask'] = mask; out['vol_nan'] = vn; out['norm_masked'] = r
+    for nm, v in (('zeros', np.zeros((4, 4, 3))), ('flat', np.full((4, 4, 3), 7.0))):
+        r = V['robust_minmax_to_minus1_1'](v)
+        assert np.array_equal(r, O.robust_minmax_to_minus1_1(v)) and r.dtype == np.float32
+        out[f'norm_{nm}'] = r
+    bounds = []
+    for z, hr in ((11, 3), (11, 80), (155, 80), (1, 0), (6, 2)):
+        vol = rng.standard_normal((3, 2, z)).astype(np.float32)
+        sl, s0, s1 = V['extract_center_slices'](vol, hr)
+        osl, o0, o1 = O.extract_center_slices(vol, hr)
+        assert (s0, s1) == (o0, o1) and len(sl) == len(osl) and all(np.array_equal(a, b) for a, b in zip(sl, osl))
+        rec = V['reconstruct_volume_from_slices'](sl, vol.shape, s0, s1)
+        assert np.array_equal(rec, O.reconstruct_volume_from_slices(osl, vol.shape, o0, o1))
+        bounds.append((z, hr, s0, s1, len(sl)))
+    out['slice_bounds'] = np.asarray(bounds, dtype=np.int64)
+    REPORT.append(('volume.slices', 0.0))
+    # bilinear resize (F.interpolate, align_corners=False) as the reference calls it: down, up, non-square, 240 -> 256
+    g = torch.Generator().manual_seed(5)
+    for tag, shp, size in (('down', (3, 1, 20, 24), (16, 16)), ('up', (2, 1, 12, 10), (32, 32)), ('x8', (2, 1, 4, 4), (32, 32)),
+                           ('brats', (1, 1, 240, 240), (256, 256)), ('same', (1, 1, 16, 16), (16, 16))):
+        x = torch.randn(*shp, generator=g)
+        y = F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+        check(f'resize.{tag}', O.resize_bilinear(x, size), y, 0)
+        out[f'resize.{tag}.in'] = x; out[f'resize.{tag}.out'] = y
+    # uncertainty map: the reference's own conv2d factory (backbones/dense_layer.py) for att_conv, then sigmoid + resize
+    from backbones.dense_layer import conv2d as R_conv2d
+    att = R_conv2d(64 * 8, 1, 1, padding=0)
+    att.weight.data = 0.05 * torch.randn(att.weight.shape, generator=g); att.bias.data = 0.1 * torch.randn(1, generator=g)
+    feat = torch.randn(2, 512, 8, 8, generator=g)
+    y = F.interpolate(torch.sigmoid(att(feat)), size=(64, 64), mode='bilinear', align_corners=False)
+    check('uncertainty_map', O.uncertainty_map(feat, att.weight, att.bias, (64, 64)), y, 0)
+    out.update({'att.feat': feat, 'att.w': att.weight.detach(), 'att.b': att.bias.detach(), 'att.out': y})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true', help='validate the oracle only, write nothing')
     ap.add_argument('--skip-full', action='store_true')
     ap.add_argument('--only-cfg5', action='store_true', help='(re)generate full_cfg5.npz alone')
+    ap.add_argument('--only-volume', action='store_true', help='(re)generate volume.npz alone')
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.only_volume:
+        d = t2n(golden_volume())
+        if not a.check:
+            np.savez_compressed(os.path.join(HERE, 'volume.npz'), **d)
+            print('wrote volume.npz', f'{os.path.getsize(os.path.join(HERE, "volume.npz")) / 1e6:.2f} MB')
+        return
     if a.only_cfg5:
         d = golden_cfg5()
         if not a.check:
@@ -414,6 +489,7 @@ def main():
         'blocks.npz': t2n(golden_blocks()),
         'small_models.npz': t2n(golden_small_models()),
         'critic.npz': t2n(golden_discriminator()),
+        'volume.npz': t2n(golden_volume()),
     }
     if not a.skip_full:
         u8, full = golden_full()

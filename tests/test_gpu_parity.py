@@ -423,3 +423,106 @@ def test_cpu_tensors_fail_loudly():
     z = torch.zeros(1, 1, 32, 32)
     with pytest.raises(mudiff_hip.MudiffHipError):
         m(z, z, z, z, torch.zeros(1, dtype=torch.int64), torch.zeros(1, cfg.nz))
+
+
+# ----------------------------------------------------------------------------------------------
+# rows f1 (uncertainty map) and f3 (volume pipeline)
+# ----------------------------------------------------------------------------------------------
+def test_resize_bilinear_and_range_kernels():
+    """F.interpolate(mode='bilinear', align_corners=False) as the reference calls it; fp32 separable weights in the same
+    order, products un-contracted: <= 1e-6 of the reference's outputs (bit-exact in practice)."""
+    ops, *_ = _imports()
+    gd = load_golden('volume.npz')
+    for tag in ('down', 'up', 'x8', 'brats', 'same'):
+        want = gd[f'resize.{tag}.out']
+        got = ops.resize_bilinear(g(gd[f'resize.{tag}.in']), want.shape[-2:])
+        assert got.shape == want.shape and maxdiff(got, want) <= 1e-6, tag
+    x = torch.randn(3, 1, 17, 5) * 1.5
+    assert torch.equal(ops.to_range_0_1(g(x)).cpu(), ((x + 1.0) / 2.0).clamp(0.0, 1.0))
+    assert ops.resize_bilinear(g(torch.zeros(0, 1, 4, 4)), (8, 8)).shape == (0, 1, 8, 8)
+
+
+def test_uncertainty_map_vs_reference():
+    from backbones.discriminator import uncertainty_map, conv2d
+    gd = load_golden('volume.npz')
+    att = conv2d(64 * 8, 1, 1, padding=0)
+    att.weight.data.copy_(gd['att.w']); att.bias.data.copy_(gd['att.b'])
+    att = att.to(DEV)
+    out = uncertainty_map(att, g(gd['att.feat']), (64, 64))
+    assert out.shape == gd['att.out'].shape and maxdiff(out, gd['att.out']) <= 1e-4
+    att.weight.mul_(2.0)                                     # in-place update (as an optimizer does it) invalidates the packed copy
+    out2 = uncertainty_map(att, g(gd['att.feat']), (64, 64))
+    assert maxdiff(out2, O.uncertainty_map(gd['att.feat'], 2 * gd['att.w'], gd['att.b'], (64, 64))) <= 1e-4
+
+
+def _volume_case():
+    gd = load_golden('volume.npz')
+    cfg = O.default_config(image_size=16, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(8,), num_res_blocks=1)
+    vols = [gd[f'vol{m}'].numpy() for m in range(3)]          # [20,24,11] float64: resized to 16x16 on the way in
+    half = 2                                                  # slices 3..7 -> n = 5
+    n, T, S = 5, cfg.num_timesteps, cfg.image_size
+    gen = torch.Generator().manual_seed(77)
+    x_inits = torch.randn(n, 1, S, S, generator=gen)
+    zs = [torch.randn(n, cfg.nz, generator=gen) for _ in range(T)]
+    noises = [torch.randn(n, 1, S, S, generator=gen) for _ in range(T)]
+    return cfg, vols, half, x_inits, zs, noises
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_volume_slices_batched_vs_per_slice_oracle(use_graph):
+    """Row f3: all slices of a volume batched (batch 2 -> 3 launches, the last one padded) through the HIP sampler vs the
+    oracle's per-slice restatement of engine/test_volume.py:262-283 with the same per-slice Gaussian draws."""
+    from mudiff_hip import volume as V
+    cfg, vols, half, x_inits, zs, noises = _volume_case()
+    g1, g2 = _build(cfg, seed=9)
+    stacks = [np.stack(V.extract_center_slices(V.robust_minmax_to_minus1_1(v), half)[0], 0) for v in vols]
+    got = V.predict_slices(cfg, g1, g2, stacks, DEV, batch_size=2, x_inits=x_inits, zs=zs, noises=noises, use_graph=use_graph)
+    sd1, sd2 = O.make_state_dict(cfg, 'g1', 9), O.make_state_dict(cfg, 'g2', 9)
+    want, s0, s1 = O.predict_volume(O.PosteriorCoefficients(cfg), sd1, sd2, cfg, vols, half,
+                                    [x_inits[i:i + 1] for i in range(5)],
+                                    [[z[i:i + 1] for z in zs] for i in range(5)], [[e[i:i + 1] for e in noises] for i in range(5)])
+    assert (s0, s1) == (3, 7) and got.shape == (5, 16, 16)
+    err = max(float(np.abs(got[i] - want[i]).max()) for i in range(5))
+    print(f'volume slices (graph={use_graph}): max-abs {err:.2e}')
+    assert err <= 1e-3 and got.min() >= 0.0 and got.max() <= 1.0
+
+
+def test_predict_volume_end_to_end_nifti(tmp_path):
+    """The CLI entry point on files: three NIfTI inputs + DDP-style checkpoints ('module.' prefix) -> predicted_t1ce.nii.gz
+    with the inputs' geometry, zero outside the centre window, [0,1] inside, reproducible for a fixed --seed; in-plane size
+    != image_size is refused unless --resize_back."""
+    from mudiff_hip import volume as V
+    cfg = O.default_config(image_size=16, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(4,), num_res_blocks=1)
+    exp = tmp_path / 'results' / 'exp0'
+    exp.mkdir(parents=True)
+    for which, name in (('g1', 'gen_diffusive_1'), ('g2', 'gen_diffusive_2')):
+        sd = O.make_state_dict(cfg, which, 9)
+        torch.save({'module.' + k: v for k, v in sd.items()}, str(exp / f'{name}.pth'))
+    rng = np.random.default_rng(0)
+    aff = np.diag([1.0, 1.0, 2.5, 1.0]); aff[:3, 3] = (-8, -8, 3)
+    paths = {}
+    for m in ('flair', 't2', 't1'):
+        v = (100 + 50 * rng.random((16, 16, 9))) * (rng.random((16, 16, 9)) > 0.2)
+        paths[m] = str(tmp_path / f'{m}.nii.gz')
+        V.write_nifti(paths[m], v.astype(np.float32), aff)
+    common = ['--target_modality', 'T1CE', '--exp', 'exp0', '--output_path', str(tmp_path / 'results'), '--image_size', '16',
+              '--num_channels_dae', '16', '--ch_mult', '1', '2', '--attn_resolutions', '4', '--num_res_blocks', '1',
+              '--slice_half_range', '2', '--batch_size', '4', '--input_flair', paths['flair'], '--input_t2', paths['t2'],
+              '--input_t1', paths['t1']]
+    outs = []
+    for run in range(2):
+        out = V.predict_volume(V.build_argparser(common + ['--output_dir', str(tmp_path / f'out{run}')]))
+        data, a, _ = V.read_nifti(out)
+        assert out.endswith('predicted_t1ce.nii.gz') and data.shape == (16, 16, 9) and np.allclose(a, aff)
+        assert not data[:, :, :2].any() and not data[:, :, 7:].any() and data[:, :, 2:7].any()
+        assert data.min() >= 0.0 and data.max() <= 1.0
+        outs.append(data)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-4      # same draws; GroupNorm sums are fp64 atomics, so not bit-for-bit
+    with pytest.raises(ValueError):                                                     # missing modality
+        V.predict_volume(V.build_argparser(common[:-2] + ['--output_dir', str(tmp_path / 'o')]))
+    big = common + ['--output_dir', str(tmp_path / 'o2')]
+    big[big.index('--image_size') + 1] = '32'
+    with pytest.raises(ValueError):
+        V.predict_volume(V.build_argparser(big))
+    out = V.predict_volume(V.build_argparser(big + ['--resize_back']))
+    assert V.read_nifti(out)[0].shape == (16, 16, 9)
