@@ -165,6 +165,9 @@ int mud_gate_mix(const float* g, int ldg, const float* att, int lda, const float
 /* ---- rows f1 / f3: bilinear resize of planes [P,H,W] -> [P,Ho,Wo] with torch F.interpolate(mode='bilinear',
  *      align_corners=False) semantics (engine/test_volume.py:274 slice -> image_size; engine/train.py:959 uncertainty map),
  *      and out = clamp(x*scale + shift, lo, hi) (the [-1,1] -> [0,1] mapping, engine/test_volume.py:281). */
+/* row f4: Gaussian Fourier features of log(t) (layerspp.py:68-77, ncsnpp_generator_adagn_feat.py:288-289):
+ * out[b, k] = sin(2*pi*W[k]*log(t[b])), out[b, n+k] = cos(...); out is [B, 2n]. */
+int mud_fourier_embedding(const float* t, const float* W, float* out, int B, int n, void* stream);
 int mud_resize_bilinear(const float* in, int64_t planes, int H, int W, int Ho, int Wo, float* out, void* stream);
 int mud_affine_clamp(const float* x, int64_t n, float scale, float shift, float lo, float hi, float* out, void* stream);
 

@@ -1,4 +1,3 @@
-import os
 """NCSN++ building blocks with AdaGN (reference backbones/layerspp.py), MI355X-native.
 
 Every block keeps the reference's class name, constructor signature, parameter names/shapes and
@@ -165,41 +164,70 @@ class AttnBlockpp(nn.Module, _Prepared):
 
 
 class Upsample(nn.Module):
-    """FIR x2 up-sampling (reference layerspp.py:141-173).  Only the with_conv=False, fir=True form is
-    reachable in the default config family (and even that only with progressive='output_skip')."""
-
-    def __init__(self, in_ch=None, out_ch=None, with_conv=False, fir=False, fir_kernel=(1, 3, 3, 1)):
-        super().__init__()
-        out_ch = out_ch if out_ch else in_ch
-        if with_conv or not fir:
-            raise NotImplementedError('Upsample(with_conv=True) / fir=False: alternate config (SURVEY.md section 8 f4)')
-        self.fir, self.with_conv, self.fir_kernel, self.out_ch = fir, with_conv, fir_kernel, out_ch
-
-    def forward(self, x):
-        return up_or_down_sampling.upsample_2d(x, self.fir_kernel, factor=2)
-
-
-class Downsample(nn.Module):
-    """FIR x2 down-sampling, optionally followed by the strided 3x3 conv (reference layerspp.py:176-210):
-    the input-pyramid branch of the generators."""
+    """x2 up-sampling (reference layerspp.py:141-173).  Reachable in the reference only as the parameter-free image-pyramid
+    up-sampler of progressive='output_skip' with fir=True (FIR x2).  The other forms are constructed like the reference
+    does (same parameters) but cannot run there either: fir=False passes 'nearest' as F.interpolate's scale_factor (:164,
+    ValueError) and fir=True/with_conv=True ends in upsample_conv_2d, which raises - `forward` raises the same way."""
 
     def __init__(self, in_ch=None, out_ch=None, with_conv=False, fir=False, fir_kernel=(1, 3, 3, 1)):
         super().__init__()
         out_ch = out_ch if out_ch else in_ch
         if not fir:
-            raise NotImplementedError('Downsample(fir=False): alternate config (SURVEY.md section 8 f4)')
-        if with_conv:
+            if with_conv:
+                self.Conv_0 = conv3x3(in_ch, out_ch)
+        elif with_conv:
+            self.Conv2d_0 = up_or_down_sampling.Conv2d(in_ch, out_ch, kernel=3, up=True, resample_kernel=fir_kernel,
+                                                       use_bias=True, kernel_init=default_init())
+        self.fir, self.with_conv, self.fir_kernel, self.out_ch = fir, with_conv, fir_kernel, out_ch
+
+    def run(self, x: View):
+        assert self.fir and not self.with_conv
+        return up_or_down_sampling.resample_view(x, 'up', True, self.fir_kernel)
+
+    def forward(self, x):
+        if not self.fir:
+            raise ValueError("only one of size or scale_factor should be defined (the reference's Upsample(fir=False) fails "
+                             'with this error at layerspp.py:164)')
+        if self.with_conv:
+            return self.Conv2d_0(x)          # raises, like the reference's upsample_conv_2d
+        return up_or_down_sampling.upsample_2d(x, self.fir_kernel, factor=2)
+
+
+class Downsample(nn.Module):
+    """x2 down-sampling (reference layerspp.py:176-210).  with_conv=True is the input-pyramid branch of
+    progressive_input='residual': FIR + strided 3x3 conv (fir=True) or zero-pad right/bottom + stride-2 3x3 conv
+    (fir=False).  with_conv=False is the parameter-free pyramid of progressive_input='input_skip': FIR /2 or 2x2 mean."""
+
+    def __init__(self, in_ch=None, out_ch=None, with_conv=False, fir=False, fir_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        if not fir:
+            if with_conv:
+                self.Conv_0 = conv3x3(in_ch, out_ch, stride=2, padding=0)
+        elif with_conv:
             self.Conv2d_0 = up_or_down_sampling.Conv2d(in_ch, out_ch, kernel=3, down=True, resample_kernel=fir_kernel,
                                                        use_bias=True, kernel_init=default_init())
         self.fir, self.fir_kernel, self.with_conv, self.out_ch = fir, fir_kernel, with_conv, out_ch
+        self._prep = None
+
+    def _naive_weights(self, mfma):
+        w = self.Conv_0.weight
+        key = (w._version, w.data_ptr(), mfma)
+        if self._prep is None or self._prep[0] != key:
+            with torch.no_grad():
+                self._prep = (key, ops.pack_conv_weight(w) if mfma else ops.direct_weight(w))
+        return self._prep[1]
 
     def run(self, x: View, res: View = None, out_scale=1.0, out: View = None):
-        assert self.with_conv
-        return self.Conv2d_0.run(x, res=res, out_scale=out_scale, out=out)
+        if self.with_conv and self.fir:
+            return self.Conv2d_0.run(x, res=res, out_scale=out_scale, out=out)
+        if self.with_conv:      # F.pad(x, (0,1,0,1)) + conv3x3(stride 2, padding 0): an identity "FIR" that only pads
+            return up_or_down_sampling.padded_strided_conv(x, np.ones((1, 1), np.float32), (0, 1), self._naive_weights, 3,
+                                                           self.Conv_0.weight.shape[0], self.Conv_0.bias.detach(), res, out_scale, out)
+        assert res is None and out is None
+        return up_or_down_sampling.resample_view(x, 'down', self.fir, self.fir_kernel)
 
     def forward(self, x):
-        if not self.with_conv:
-            return up_or_down_sampling.downsample_2d(x, self.fir_kernel, factor=2)
         return self.run(View.from_nchw(x)).to_nchw()
 
 
@@ -210,8 +238,6 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
                  fir_kernel=(1, 3, 3, 1), skip_rescale=True, init_scale=0.):
         super().__init__()
         out_ch = out_ch if out_ch else in_ch
-        if (up or down) and not fir:
-            raise NotImplementedError('fir=False resampling: alternate config (SURVEY.md section 8 f4)')
         if not isinstance(act, nn.SiLU):
             raise NotImplementedError('only the SiLU activation of the reference generators is built')
         self.GroupNorm_0 = AdaptiveGroupNorm(min(in_ch // 4, 32), in_ch, zemb_dim)
@@ -249,12 +275,12 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         p = self.prepared()
         sc0, sh0 = self.GroupNorm_0.scale_shift(x, style0)
         if self.up:
-            kk, up, down, pad = up_or_down_sampling.fir_params('up', self.fir_kernel)
+            kk, up, down, pad = up_or_down_sampling.fir_params('up' if self.fir else 'naive_up', self.fir_kernel)
             h_in, _ = ops.fir_nhwc(x, kk, up, down, pad, pro=(sc0, sh0, PRO_AFFINE_SILU), want_h=True, want_x=False)
             x_skip, _ = ops.fir_nhwc(p['c2'](x), kk, up, down, pad)          # = Conv_2(FIR(x)) minus its bias (see _prepare)
             h = p['c0'](h_in, bias2=tbias, arena=arena)
         elif self.down:
-            kk, up, down, pad = up_or_down_sampling.fir_params('down', self.fir_kernel)
+            kk, up, down, pad = up_or_down_sampling.fir_params('down' if self.fir else 'naive_down', self.fir_kernel)
             h_in, x_skip = ops.fir_nhwc(x, kk, up, down, pad, pro=(sc0, sh0, PRO_AFFINE_SILU), want_h=True, want_x=True)
             h = p['c0'](h_in, bias2=tbias, arena=arena)
         else:
@@ -350,15 +376,63 @@ class ConvBlock_GAP(nn.Module, _Prepared):
         return self.run(View.from_nchw(x))
 
 
-def _alternate(name):
-    class _NotBuilt(nn.Module):
+class GaussianFourierProjection(nn.Module):
+    """Gaussian Fourier embedding of noise levels (reference layerspp.py:68-77); W is a frozen parameter."""
+
+    def __init__(self, embedding_size=256, scale=1.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embedding_size) * scale, requires_grad=False)
+
+    def run_log(self, t):
+        """Embedding of log(t) - the form the generators use (ncsnpp_generator_adagn_feat.py:288-289) - in one kernel."""
+        return ops.fourier_embedding(t, self.W)
+
+    def forward(self, x):
+        return ops.fourier_embedding(torch.exp(x.float()), self.W)
+
+
+class Combine(nn.Module, _Prepared):
+    """conv1x1 of the image pyramid, then sum with / concatenation to the feature map (reference layerspp.py:80-95)."""
+
+    def __init__(self, dim1, dim2, method='cat'):
+        super().__init__()
+        self.Conv_0 = conv1x1(dim1, dim2)
+        self.method = method
+        if method not in ('cat', 'sum'):
+            raise ValueError(f'Method {method} not recognized.')
+
+    def _prepare(self):
+        return dict(c=ConvParam(self.Conv_0))
+
+    def run(self, x: View, y: View, out: View = None):
+        """sum: out = conv(x) + y (one launch, y enters the epilogue).  cat: `out` is the [.., 2*dim2] concat buffer whose
+        second half `y` already occupies (its producer wrote it there); the conv fills the first half."""
+        p = self.prepared()
+        if self.method == 'sum':
+            return p['c'](x, res=y, out=out)
+        d = self.Conv_0.weight.shape[0]
+        if out is None:
+            out = View.empty(y.B, y.H, y.W, 2 * d, y.device)
+            out.slice(d, d).tensor().copy_(y.tensor())          # standalone use only (plumbing copy)
+        else:
+            assert y.base is out.base and y.c0 == out.c0 + d, 'Combine(cat): y must already live in the second half of `out`'
+        p['c'](x, out=out.slice(0, d))
+        return out
+
+    def forward(self, x, y):
+        return self.run(View.from_nchw(x), View.from_nchw(y)).to_nchw()
+
+
+def _unbuildable(name, why):
+    class _Unbuildable(nn.Module):
         def __init__(self, *a, **k):
-            raise NotImplementedError(f'{name}: alternate-config block (SURVEY.md section 8 f4), not built yet')
-    _NotBuilt.__name__ = name
-    return _NotBuilt
+            raise NotImplementedError(f'{name}: {why}')
+    _Unbuildable.__name__ = name
+    return _Unbuildable
 
 
-GaussianFourierProjection = _alternate('GaussianFourierProjection')
-Combine = _alternate('Combine')
-ResnetBlockDDPMpp_Adagn = _alternate('ResnetBlockDDPMpp_Adagn')
-ResnetBlockBigGANpp_Adagn_one = _alternate('ResnetBlockBigGANpp_Adagn_one')
+# The generators of the reference cannot be constructed with these block types (resblock_type='ddpm' /
+# 'biggan_oneadagn' hit an UnboundLocalError on `ConvBlock`, ncsnpp_generator_adagn_feat.py:177-180), so no checkpoint and
+# no caller can exist for them; tests/golden/make_golden.py records the failure.
+ResnetBlockDDPMpp_Adagn = _unbuildable('ResnetBlockDDPMpp_Adagn', "unreachable: the reference's generators fail to construct with resblock_type='ddpm'")
+ResnetBlockBigGANpp_Adagn_one = _unbuildable('ResnetBlockBigGANpp_Adagn_one', "unreachable: the reference's generators fail to construct with resblock_type='biggan_oneadagn'")

@@ -12,10 +12,14 @@ torch arithmetic: it schedules hand-written gfx950 kernels (libmudiff_hip.so) on
     views of shared buffers (the producer writes straight into its slot; nothing is copied);
   * tail: GroupNorm+SiLU prologue, 3x3 conv to one channel, tanh epilogue in one direct kernel.
 
-Supported: the default configuration family (resblock_type='biggan', fir=True, progressive='none',
-progressive_input='residual', embedding_type='positional', conditional=True) with any nf / ch_mult /
-num_res_blocks / attn_resolutions / image size.  Other variants raise NotImplementedError (SURVEY.md
-section 8 row f4).  GPU tensors only; ambient autocast is ignored (fp32 in, fp32 out).
+Supported: every configuration the reference itself can construct and run (probed and
+recorded by tests/golden/make_golden.py::golden_variants) - embedding_type positional | fourier, conditional on/off,
+progressive none | output_skip, progressive_input residual | input_skip (sum | cat) | none, fir on/off, skip_rescale
+on/off, centered / not_use_tanh, any nf / ch_mult / num_res_blocks / attn_resolutions / image size, num_channels > 1
+for G1, and the two-condition twins (ncsnpp_generator_adagn_feat_healthy.py).  resblock_type 'ddpm' / 'biggan_oneadagn',
+progressive='residual' and fir=False with progressive='output_skip' raise inside the reference's own constructor /
+forward; they raise NotImplementedError here with that explanation.  GPU tensors only; ambient autocast is ignored
+(fp32 in, fp32 out).
 """
 import functools
 
@@ -49,21 +53,27 @@ class PixelNorm(nn.Module):
 def _check_config(config):
     problems = []
     if config.resblock_type.lower() != 'biggan':
-        problems.append(f"resblock_type={config.resblock_type!r}")
-    if config.progressive.lower() != 'none':
-        problems.append(f"progressive={config.progressive!r}")
-    if config.progressive_input.lower() != 'residual':
-        problems.append(f"progressive_input={config.progressive_input!r}")
-    if config.embedding_type.lower() != 'positional':
-        problems.append(f"embedding_type={config.embedding_type!r}")
-    if not (config.conditional and config.fir and config.resamp_with_conv):
-        problems.append('conditional/fir/resamp_with_conv must all be True')
+        if config.resblock_type.lower() not in ('ddpm', 'biggan_oneadagn'):
+            raise ValueError(f'resblock type {config.resblock_type.lower()} unrecognized.')
+        problems.append(f"resblock_type={config.resblock_type!r} (UnboundLocalError on ConvBlock in the reference constructor, :177-180)")
+    prog = config.progressive.lower()
+    if prog not in ('none', 'output_skip', 'residual'):
+        raise ValueError(f'{prog} is not a valid name.')
+    if prog == 'residual':
+        problems.append("progressive='residual' (the reference's Conv2d(up=True) raises in forward)")
+    if prog == 'output_skip' and not config.fir:
+        problems.append("progressive='output_skip' with fir=False (the reference's Upsample(fir=False) raises, layerspp.py:164)")
+    if config.progressive_input.lower() not in ('none', 'input_skip', 'residual'):
+        raise ValueError(f'progressive_input {config.progressive_input!r} unknown.')
+    if config.embedding_type.lower() not in ('positional', 'fourier'):
+        raise ValueError(f'embedding type {config.embedding_type.lower()} unknown.')
     if problems:
-        raise NotImplementedError('alternate NCSN++ config not built yet (SURVEY.md section 8 f4): ' + ', '.join(problems))
+        raise NotImplementedError('this configuration cannot be built or run by the reference either: ' + '; '.join(problems))
 
 
 class _NCSNppBase(nn.Module, layerspp._Prepared):
     ADAPTIVE = False
+    N_COND = 3          # 2 in ncsnpp_generator_adagn_feat_healthy.py
 
     def __init__(self, config):
         super().__init__()
@@ -79,43 +89,56 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         dropout = config.dropout
         self.num_resolutions = num_resolutions = len(ch_mult)
         self.all_resolutions = all_resolutions = [config.image_size // (2 ** i) for i in range(num_resolutions)]
-        self.conditional = config.conditional
+        self.conditional = conditional = config.conditional
         fir, fir_kernel = config.fir, config.fir_kernel
         self.skip_rescale = skip_rescale = config.skip_rescale
         self.resblock_type = config.resblock_type.lower()
-        self.progressive = config.progressive.lower()
-        self.progressive_input = config.progressive_input.lower()
-        self.embedding_type = config.embedding_type.lower()
+        self.progressive = progressive = config.progressive.lower()
+        self.progressive_input = progressive_input = config.progressive_input.lower()
+        self.embedding_type = embedding_type = config.embedding_type.lower()
+        combine_method = config.progressive_combine.lower()
         init_scale = 0.
         channels = config.num_channels
 
         ResnetBlock = functools.partial(ResnetBlockBigGAN, act=act, dropout=dropout, fir=fir, fir_kernel=fir_kernel,
                                         init_scale=init_scale, skip_rescale=skip_rescale, temb_dim=nf * 4, zemb_dim=z_emb_dim)
         AttnBlock = functools.partial(layerspp.AttnBlockpp, init_scale=init_scale, skip_rescale=skip_rescale)
+        if progressive == 'output_skip':
+            self.pyramid_upsample = layerspp.Upsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
+        if progressive_input == 'input_skip':
+            self.pyramid_downsample = layerspp.Downsample(fir=fir, fir_kernel=fir_kernel, with_conv=False)
         pyramid_downsample = functools.partial(layerspp.Downsample, fir=fir, fir_kernel=fir_kernel, with_conv=True)
 
-        modules = [nn.Linear(nf, nf * 4), nn.Linear(nf * 4, nf * 4)]
-        for lin in modules:
-            lin.weight.data = default_initializer()(lin.weight.shape)
-            nn.init.zeros_(lin.bias)
-
+        modules = []
         self._plan = plan = []            # (kind, module index, ...) walked by forward
 
         def add(kind, mod, **kw):
             modules.append(mod)
             plan.append(dict(kind=kind, idx=len(modules) - 1, **kw))
 
+        embed_dim = nf
+        if embedding_type == 'fourier':
+            add('fourier', layerspp.GaussianFourierProjection(embedding_size=nf, scale=config.fourier_scale))
+            embed_dim = 2 * nf
+        if conditional:
+            for lin in (nn.Linear(embed_dim, nf * 4), nn.Linear(nf * 4, nf * 4)):
+                lin.weight.data = default_initializer()(lin.weight.shape)
+                nn.init.zeros_(lin.bias)
+                add('temb', lin)
+
         if not self.ADAPTIVE:
-            for _ in range(4):
+            for _ in range(1 + self.N_COND):
                 add('feat', ResnetBlock_Feat(act=act, in_ch=channels, out_ch=nf))
+            head_c = nf * (1 + self.N_COND)
         else:
             add('gap', ResnetBlock_Feat_GAP(act=act, in_ch=channels, out_ch=nf))
             add('feat', ResnetBlock_Feat(act=act, in_ch=channels, out_ch=nf))
-            for _ in range(3):
+            for _ in range(self.N_COND):
                 add('ada', ResnetBlock_Adapt_Feat(act=act, in_ch=channels, out_ch=nf))
+            head_c = nf * (4 if self.N_COND == 3 else 2)      # x_feat + one fused map per pair (reference :790 / healthy :311)
 
-        hs_c = [nf * 4]
-        in_ch = nf * 4
+        hs_c = [head_c]
+        in_ch = head_c
         input_pyramid_ch = channels
         for i_level in range(num_resolutions):
             for _ in range(num_res_blocks):
@@ -127,8 +150,13 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
                 hs_c.append(in_ch)
             if i_level != num_resolutions - 1:
                 add('res', ResnetBlock(down=True, in_ch=in_ch), stage='downsample')
-                add('pyr', pyramid_downsample(in_ch=input_pyramid_ch, out_ch=in_ch))
-                input_pyramid_ch = in_ch
+                if progressive_input == 'input_skip':
+                    add('combine', layerspp.Combine(dim1=input_pyramid_ch, dim2=in_ch, method=combine_method))
+                    if combine_method == 'cat':
+                        in_ch *= 2
+                elif progressive_input == 'residual':
+                    add('pyr', pyramid_downsample(in_ch=input_pyramid_ch, out_ch=in_ch))
+                    input_pyramid_ch = in_ch
                 hs_c.append(in_ch)
         self._hs_channels = list(hs_c)
         in_ch = hs_c[-1]
@@ -137,15 +165,14 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         add('res', ResnetBlock(in_ch=in_ch), stage='mid')
 
         if self.ADAPTIVE:   # registered BEFORE all_modules, like the reference (state_dict order)
-            self.feat_weight_c1 = conv3x3(nf, nf)
-            self.feat_weight_c2 = conv3x3(nf, nf)
-            self.feat_weight_c3 = conv3x3(nf, nf)
-            self.feat_att1_c12 = conv3x3(3 * nf, nf)
-            self.feat_att2_c12 = conv3x3(3 * nf, nf)
-            self.feat_att1_c23 = conv3x3(3 * nf, nf)
-            self.feat_att2_c23 = conv3x3(3 * nf, nf)
-            self.feat_att1_c31 = conv3x3(3 * nf, nf)
-            self.feat_att2_c31 = conv3x3(3 * nf, nf)
+            nc = self.N_COND
+            pairs = ('c12', 'c23', 'c31') if nc == 3 else ('c12',)
+            for j in range(len(pairs)):
+                setattr(self, f'feat_weight_c{j + 1}', conv3x3(nf, nf))
+            for pair in pairs:
+                setattr(self, f'feat_att1_{pair}', conv3x3(nc * nf, nf))
+                setattr(self, f'feat_att2_{pair}', conv3x3(nc * nf, nf))
+            self._pairs = pairs
 
         for i_level in reversed(range(num_resolutions)):
             for _ in range(num_res_blocks + 1):
@@ -154,11 +181,17 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
                 in_ch = out_ch
             if all_resolutions[i_level] in attn_resolutions:
                 add('attn', AttnBlock(channels=in_ch), stage='up')
+            if progressive == 'output_skip':
+                first = i_level == num_resolutions - 1
+                add('gn', nn.GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6), stage='pyramid')
+                add('conv', conv3x3(in_ch, channels, init_scale=init_scale) if first else conv3x3(in_ch, channels, bias=True, init_scale=init_scale),
+                    stage='pyramid', first=first, last=i_level == 0)
             if i_level != 0:
                 add('res', ResnetBlock(in_ch=in_ch, up=True), stage='upsample')
         assert not hs_c
-        add('gn', nn.GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6))
-        add('conv', conv3x3(in_ch, channels, init_scale=init_scale))
+        if progressive != 'output_skip':
+            add('gn', nn.GroupNorm(num_groups=min(in_ch // 4, 32), num_channels=in_ch, eps=1e-6), stage='tail')
+            add('conv', conv3x3(in_ch, channels, init_scale=init_scale), stage='tail')
 
         self.all_modules = nn.ModuleList(modules)
 
@@ -191,18 +224,17 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         p = dict(offs=offs,
                  style_w=torch.cat(style_w, 0).contiguous(), style_b=torch.cat(style_b, 0).contiguous(),
                  dense_w=torch.cat(dense_w, 0).contiguous(), dense_b=torch.cat(dense_b, 0).contiguous())
-        tail_conv = mods[self._plan[-1]['idx']]
-        p['tail'] = layerspp.ConvParam(tail_conv)
+        p['convs'] = {e['idx']: layerspp.ConvParam(mods[e['idx']]) for e in self._plan if e['kind'] == 'conv'}
         if self.ADAPTIVE:
-            # the six sigmoid gate convs share their input (reference :769-776): two convs of 3*nf output channels -
+            # the sigmoid gate convs share their input (reference :769-776): two convs of n_pairs*nf output channels -
             # the att1 gates (multiplied by the feature they gate in the epilogue) and the att2 gates
-            for key, gates in (('g1', (self.feat_att1_c12, self.feat_att1_c23, self.feat_att1_c31)),
-                               ('g2', (self.feat_att2_c12, self.feat_att2_c23, self.feat_att2_c31))):
-                wg = torch.cat([g.weight for g in gates], 0).contiguous()          # [3nf, 3nf, 3, 3]
+            for key, pre in (('g1', 'feat_att1_'), ('g2', 'feat_att2_')):
+                gates = [getattr(self, pre + pair) for pair in self._pairs]
+                wg = torch.cat([g.weight for g in gates], 0).contiguous()          # [n_pairs*nf, n_cond*nf, 3, 3]
                 p[key + '_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
                 p[key + '_w'] = ops.pack_conv_weight(wg) if p[key + '_mfma'] else ops.direct_weight(wg)
                 p[key + '_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
-            p['fw'] = [layerspp.ConvParam(c) for c in (self.feat_weight_c1, self.feat_weight_c2, self.feat_weight_c3)]
+            p['fw'] = [layerspp.ConvParam(getattr(self, f'feat_weight_c{j + 1}')) for j in range(len(self._pairs))]
             ada = [mods[e['idx']] for e in self._plan if e['kind'] == 'ada']
             p['ada_w'] = torch.cat([m.group_norm.style.weight for m in ada], 0).contiguous()
             p['ada_b'] = torch.cat([m.group_norm.style.bias for m in ada], 0).contiguous()
@@ -215,27 +247,39 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             if isinstance(layer, nn.Linear):
                 h = ops.dense(h, layer.weight.detach(), layer.bias.detach(), act_out=ACT_SILU)
         zemb = h
-        temb = layers.get_timestep_embedding(time_cond, self.nf)
-        temb = ops.dense(temb, mods[0].weight.detach(), mods[0].bias.detach())
-        temb = ops.dense(temb, mods[1].weight.detach(), mods[1].bias.detach(), act_in=ACT_SILU)
+        if self.embedding_type == 'fourier':      # Gaussian Fourier features of log(sigma) (reference :286-290)
+            temb = mods[self._plan[0]['idx']].run_log(time_cond)
+        else:
+            temb = layers.get_timestep_embedding(time_cond, self.nf)
+        if not self.conditional:
+            return None, zemb
+        l0, l1 = (mods[e['idx']] for e in self._plan if e['kind'] == 'temb')
+        temb = ops.dense(temb, l0.weight.detach(), l0.bias.detach())
+        temb = ops.dense(temb, l1.weight.detach(), l1.bias.detach(), act_in=ACT_SILU)
         return temb, zemb
 
-    def _check_inputs(self, x, *conds):
+    def _check_inputs(self, x, conds, pseudo=None):
         ops.require_gpu(x, *conds)
+        if len(conds) != self.N_COND or any(c is None for c in conds):
+            raise TypeError(f'{type(self).__name__} takes {self.N_COND} condition images')
         B, C, H, W = x.shape
-        if C != self.config.num_channels or C != 1:
-            raise NotImplementedError(f'the MI355X build handles single-channel slices (num_channels=1), got {C}')
+        if C != self.config.num_channels:
+            raise ValueError(f'x has {C} channels, the model was built for num_channels={self.config.num_channels}')
         for c in conds:
             if tuple(c.shape) != (B, C, H, W):
                 raise ValueError(f'condition shape {tuple(c.shape)} does not match x {tuple(x.shape)}')
+        if pseudo is not None:
+            ops.require_gpu(pseudo)
+            if tuple(pseudo.shape) != (B, C, H, W):     # the reference's conv raises on a channel mismatch too
+                raise ValueError(f'pseudo_target shape {tuple(pseudo.shape)} does not match x {tuple(x.shape)}')
         if H % (2 ** (self.num_resolutions - 1)) or W % (2 ** (self.num_resolutions - 1)):
             raise ValueError(f'H, W must be divisible by {2 ** (self.num_resolutions - 1)}')
         return B, H, W
 
     def _prep_image(self, t):
         v = View.from_nchw(t.detach())
-        if not self.config.centered:   # data in [0,1] (reference :309-311); rare path, plain torch affine
-            v = View((2 * v.base - 1.).contiguous(), v.B, v.H, v.W, v.C)
+        if not self.config.centered:   # data in [0,1] (reference :309-311)
+            v = View(ops.affine_clamp(v.base, 2.0, -1.0, -float('inf'), float('inf')), v.B, v.H, v.W, v.C)
         return v
 
     def _make_buffers(self, B, H, W, dev, arena=None):
@@ -244,7 +288,7 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         ONE buffer [B,H,W,Ch+Cs]; the producer of h and the producer of skip_k write straight into
         their channel slots, so no concatenation is ever copied."""
         mods = self.all_modules
-        trunk = [e for e in self._plan if e['kind'] in ('res', 'attn', 'pyr')]
+        trunk = [e for e in self._plan if e['kind'] in ('res', 'attn', 'pyr', 'combine') or e.get('stage') in ('pyramid', 'tail')]
         sizes = [(H, W)]
         hh, ww = H, W
         for e in trunk:
@@ -271,7 +315,7 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         mods = self.all_modules
         n_skips = len(bufs)
         styles = ops.dense(zemb, p['style_w'], p['style_b'])                       # [B, sum 2C]
-        tb_all = ops.dense(temb, p['dense_w'], p['dense_b'], act_in=ACT_SILU)      # [B, sum Cout]
+        tb_all = ops.dense(temb, p['dense_w'], p['dense_b'], act_in=ACT_SILU) if temb is not None else None      # [B, sum Cout]
         rescale = INV_SQRT2 if self.skip_rescale else 1.0
 
         def res(e, x, out=None):
@@ -280,7 +324,8 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             if out is None:       # block output consumed by another GroupNorm (mid blocks, attention, upsample blocks, tail)
                 out = View.empty(x.B, x.H * (2 if m.up else 1) // (2 if m.down else 1), x.W * (2 if m.up else 1) // (2 if m.down else 1),
                                  m.out_ch, x.device, arena)
-            return m.run(x, styles[:, o0:o1], styles[:, o1:o2], tb_all[:, d0:d0 + m.out_ch], out=out, arena=arena)
+            tb = tb_all[:, d0:d0 + m.out_ch] if tb_all is not None else None
+            return m.run(x, styles[:, o0:o1], styles[:, o1:o2], tb, out=out, arena=arena)
 
         def skip_slot(k):
             buf, ch, cs = bufs[n_skips - 1 - k]
@@ -291,10 +336,11 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             return buf.slice(0, ch)
 
         def nxt_is(i, kind, stage):
-            return i + 1 < len(trunk) and trunk[i + 1]['kind'] == kind and trunk[i + 1]['stage'] == stage
+            return i + 1 < len(trunk) and trunk[i + 1]['kind'] == kind and trunk[i + 1].get('stage') == stage
 
         skips = [skip_slot(0)]
-        pyr = x_img
+        pyr = x_img if self.progressive_input != 'none' else None
+        out_pyr = None          # progressive='output_skip' image pyramid [B,h,w,channels]
         h = skips[0]
         up_j = 0
         i = 0
@@ -310,11 +356,26 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
                     h = res(e, skips[-1], out=skip_slot(len(skips)))
                 skips.append(h)
             elif kind == 'res' and stage == 'downsample':
-                hd = res(e, skips[-1])
-                i += 1
-                # input pyramid: FIR + strided conv, epilogue fuses (+bias, + hd) / sqrt2 (reference :359-366)
-                h = mods[trunk[i]['idx']].run(pyr, res=hd, out_scale=rescale, out=skip_slot(len(skips)))
-                pyr = h
+                slot = skip_slot(len(skips))
+                if nxt_is(i, 'pyr', None):
+                    hd = res(e, skips[-1])
+                    i += 1
+                    # input pyramid: FIR + strided conv, epilogue fuses (+bias, + hd) / sqrt2 (reference :359-366)
+                    h = mods[trunk[i]['idx']].run(pyr, res=hd, out_scale=rescale, out=slot)
+                    pyr = h
+                elif nxt_is(i, 'combine', None):
+                    comb = mods[trunk[i + 1]['idx']]
+                    pyr = self.pyramid_downsample.run(pyr)                     # parameter-free /2 of the image (reference :349)
+                    if comb.method == 'cat':                                    # cat([conv1x1(pyr), hd]): hd written in place
+                        d = slot.C // 2
+                        hd = res(e, skips[-1], out=slot.slice(d, d))
+                        h = comb.run(pyr, hd, out=slot)
+                    else:
+                        hd = res(e, skips[-1])
+                        h = comb.run(pyr, hd, out=slot)
+                    i += 1
+                else:                                                           # progressive_input='none'
+                    h = res(e, skips[-1], out=slot)
                 skips.append(h)
             elif kind == 'res' and stage == 'mid':
                 h = res(e, h, out=None if nxt_is(i, 'attn', 'mid') else h_slot(0))
@@ -328,30 +389,41 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
                 h = res(e, buf, out=h_slot(up_j) if nxt_is(i, 'res', 'up') else None)
             elif kind == 'res' and stage == 'upsample':
                 h = res(e, h, out=h_slot(up_j))
+            elif kind == 'gn' and stage == 'pyramid':
+                # output pyramid (reference :389-411): pyramid = up(pyramid) + conv3x3(silu(GN(h))); the sum (and the final
+                # tanh) run in the conv epilogue
+                gn = mods[e['idx']]
+                sc, sh = ops.gn_scale_shift(h, gn.num_groups, gn.weight.detach(), gn.bias.detach())
+                i += 1
+                ce = trunk[i]
+                up = None if ce['first'] else self.pyramid_upsample.run(out_pyr)
+                last_act = ACT_TANH if (ce['last'] and not self.not_use_tanh) else ACT_NONE
+                out_pyr = p['convs'][ce['idx']](h, pro=(sc, sh, PRO_AFFINE_SILU), res=up, act=last_act)
+            elif kind == 'gn' and stage == 'tail':
+                # ---- tail: GroupNorm(affine) + SiLU prologue, conv3x3 -> image channels, tanh epilogue
+                assert not skips and up_j == n_skips
+                gn = mods[e['idx']]
+                sc, sh = ops.gn_scale_shift(h, gn.num_groups, gn.weight.detach(), gn.bias.detach())
+                i += 1
+                out_pyr = p['convs'][trunk[i]['idx']](h, pro=(sc, sh, PRO_AFFINE_SILU), act=ACT_NONE if self.not_use_tanh else ACT_TANH)
             else:
                 raise AssertionError(e)
             i += 1
         assert not skips and up_j == n_skips
-        # ---- tail: GroupNorm(affine) + SiLU prologue, conv3x3 -> 1 channel, tanh epilogue
-        gn = mods[self._plan[-2]['idx']]
-        sc, sh = ops.gn_scale_shift(h, gn.num_groups, gn.weight.detach(), gn.bias.detach())
-        out = p['tail'](h, pro=(sc, sh, PRO_AFFINE_SILU), act=ACT_NONE if self.not_use_tanh else ACT_TANH)
-        return out.to_nchw()
+        return out_pyr.to_nchw()
 
 
-@utils.register_model(name='ncsnpp')
-class NCSNpp(_NCSNppBase):
-    """G1 - contrast-specific NCSN++ generator (reference :53-447)."""
+class _G1(_NCSNppBase):
     ADAPTIVE = False
 
-    def forward(self, x, cond1, cond2, cond3, time_cond, z):
+    def _forward(self, x, conds, time_cond, z):
         with torch.no_grad(), torch.autocast('cuda', enabled=False):
-            B, H, W = self._check_inputs(x, cond1, cond2, cond3)
+            B, H, W = self._check_inputs(x, conds)
             p = self.prepared()
             mods = self.all_modules
             temb, zemb = self._embeddings(time_cond, z)
             xv = self._prep_image(x)
-            imgs = [xv] + [View.from_nchw(c.detach()) for c in (cond1, cond2, cond3)]
+            imgs = [xv] + [View.from_nchw(c.detach()) for c in conds]
             nf = self.nf
             arena = ops.StatsArena(xv.device)
             trunk, bufs = self._make_buffers(B, H, W, xv.device, arena)
@@ -361,21 +433,17 @@ class NCSNpp(_NCSNppBase):
             return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)
 
 
-@utils.register_model(name='ncsnpp_adaptive')
-class NCSNpp_adaptive(_NCSNppBase):
-    """G2 - contrast-aware NCSN++ generator (reference :451-905): the three condition feature maps are
-    AdaGN-modulated by a style vector pooled from the pseudo-target (G1's prediction) and fused pairwise
-    through sigmoid gates before entering the shared trunk."""
+class _G2(_NCSNppBase):
     ADAPTIVE = True
 
-    def forward(self, x, cond1, cond2, cond3, time_cond, z, pseudo_target):
+    def _forward(self, x, conds, time_cond, z, pseudo_target):
         with torch.no_grad(), torch.autocast('cuda', enabled=False):
-            B, H, W = self._check_inputs(x, cond1, cond2, cond3, pseudo_target)
+            B, H, W = self._check_inputs(x, conds, pseudo_target)
             p = self.prepared()
             mods = self.all_modules
             temb, zemb = self._embeddings(time_cond, z)
             xv = self._prep_image(x)
-            nf, dev = self.nf, xv.device
+            nf, dev, nc = self.nf, xv.device, self.N_COND
             e_gap = next(e for e in self._plan if e['kind'] == 'gap')
             e_feat = next(e for e in self._plan if e['kind'] == 'feat')
             e_ada = [e for e in self._plan if e['kind'] == 'ada']
@@ -384,15 +452,35 @@ class NCSNpp_adaptive(_NCSNppBase):
             trunk, bufs = self._make_buffers(B, H, W, dev, arena)
             hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
             mods[e_feat['idx']].run(xv, out=hs0.slice(0, nf), arena=arena)
-            ada_styles = ops.dense(pseudo_weight, p['ada_w'], p['ada_b'])                                  # [B, 3*2nf]
-            cat = View.empty(B, H, W, 3 * nf, dev)
-            for j, (e, c) in enumerate(zip(e_ada, (cond1, cond2, cond3))):
+            ada_styles = ops.dense(pseudo_weight, p['ada_w'], p['ada_b'])                                  # [B, nc*2nf]
+            cat = View.empty(B, H, W, nc * nf, dev)
+            for j, (e, c) in enumerate(zip(e_ada, conds)):
                 mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf), arena=arena)
-            # att1 gates already multiplied by the feature they gate: sigmoid(conv(cat)) * cat (pairs gate c1, c2, c3 in
-            # this order, reference :778,783,787); att2 gates: plain sigmoid
-            gated = ops.conv(cat, p['g1_w'], 3, 3 * nf, mfma=p['g1_mfma'], bias=p['g1_b'], act=ACT_SIGMOID, emul=cat)
-            g2all = ops.conv(cat, p['g2_w'], 3, 3 * nf, mfma=p['g2_mfma'], bias=p['g2_b'], act=ACT_SIGMOID)
-            for j, b_ in enumerate((1, 2, 0)):      # fused_ij = g2 * conv(g1 * c_i) + (1 - g2) * c_j   (reference :779-788)
-                p['fw'][j](gated.slice(j * nf, nf), gate=(g2all.slice(j * nf, nf), cat.slice(b_ * nf, nf)),
+            # att1 gates already multiplied by the feature they gate: sigmoid(conv(cat)) * c_i (pair k gates c_k: c12 -> c1,
+            # c23 -> c2, c31 -> c3, reference :778,783,787); att2 gates: plain sigmoid
+            npair = len(self._pairs)
+            gated = ops.conv(cat, p['g1_w'], 3, npair * nf, mfma=p['g1_mfma'], bias=p['g1_b'], act=ACT_SIGMOID, emul=cat.slice(0, npair * nf))
+            g2all = ops.conv(cat, p['g2_w'], 3, npair * nf, mfma=p['g2_mfma'], bias=p['g2_b'], act=ACT_SIGMOID)
+            for j in range(npair):      # fused_ij = g2 * conv(g1 * c_i) + (1 - g2) * c_j   (reference :779-788)
+                other = (j + 1) % nc
+                p['fw'][j](gated.slice(j * nf, nf), gate=(g2all.slice(j * nf, nf), cat.slice(other * nf, nf)),
                            out=hs0.slice((j + 1) * nf, nf))
             return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)
+
+
+@utils.register_model(name='ncsnpp')
+class NCSNpp(_G1):
+    """G1 - contrast-specific NCSN++ generator (reference :53-447)."""
+
+    def forward(self, x, cond1, cond2, cond3, time_cond, z):
+        return self._forward(x, (cond1, cond2, cond3), time_cond, z)
+
+
+@utils.register_model(name='ncsnpp_adaptive')
+class NCSNpp_adaptive(_G2):
+    """G2 - contrast-aware NCSN++ generator (reference :451-905): the three condition feature maps are
+    AdaGN-modulated by a style vector pooled from the pseudo-target (G1's prediction) and fused pairwise
+    through sigmoid gates before entering the shared trunk."""
+
+    def forward(self, x, cond1, cond2, cond3, time_cond, z, pseudo_target):
+        return self._forward(x, (cond1, cond2, cond3), time_cond, z, pseudo_target)

@@ -27,6 +27,10 @@ def fir_params(mode, k=None, factor=2, gain=1, conv_k=3):
         kk = _setup_kernel(k) * (gain * (factor ** 2))
         p = kk.shape[0] - factor
         return kk, factor, 1, ((p + 1) // 2 + factor - 1, p // 2)
+    if mode == 'naive_up':       # nearest-neighbour repeat (naive_upsample_2d:64-68): ones(f,f), zero-stuffed input, pad (f-1, 0)
+        return np.ones((factor, factor), np.float32), factor, 1, (factor - 1, 0)
+    if mode == 'naive_down':     # box mean (naive_downsample_2d:71-74)
+        return np.full((factor, factor), 1.0 / (factor * factor), np.float32), 1, factor, (0, 0)
     kk = _setup_kernel(k) * gain
     if mode == 'down':
         p = kk.shape[0] - factor
@@ -69,11 +73,46 @@ def conv_downsample_2d(x, w, k=None, factor=2, gain=1):
 
 
 def naive_upsample_2d(x, factor=2):
-    raise NotImplementedError('fir=False resamplers are an alternate config (SURVEY.md section 8 f4), not built yet')
+    """Nearest-neighbour repeat (reference :64-68) on the same up-FIR-down kernel: exact (one tap of weight 1)."""
+    kk, up, down, pad = fir_params('naive_up', factor=factor)
+    return upfirdn2d(x, _device_kernel(kk, x.device), up=up, pad=pad)
 
 
 def naive_downsample_2d(x, factor=2):
-    raise NotImplementedError('fir=False resamplers are an alternate config (SURVEY.md section 8 f4), not built yet')
+    """factor x factor box mean (reference :71-74)."""
+    kk, up, down, pad = fir_params('naive_down', factor=factor)
+    return upfirdn2d(x, _device_kernel(kk, x.device), down=down, pad=pad)
+
+
+def resample_view(x: View, direction, fir, fir_kernel):
+    """Parameter-free x2 resampling of an NHWC view (Upsample / Downsample with_conv=False): the single-channel image
+    pyramids go through the planes kernel (NHWC == planes when C == 1), feature maps through the NHWC kernel."""
+    kk, up, down, pad = fir_params(direction if fir else 'naive_' + direction, fir_kernel)
+    if x.C % 4 == 0:
+        return ops.fir_nhwc(x, kk, up, down, pad)[0]
+    assert x.ld == x.C, 'planes path needs a dense view'
+    t = x.base.reshape(x.B, x.H, x.W, x.C)
+    planes = t.reshape(x.B, 1, x.H, x.W) if x.C == 1 else t.permute(0, 3, 1, 2).contiguous()
+    r = upfirdn2d(planes, _device_kernel(kk, x.device), up=up, down=down, pad=pad)
+    return View.from_nchw(r)
+
+
+def padded_strided_conv(x: View, kk, pad, weights, ks, cout, bias, res, out_scale, out):
+    """FIR `kk` with padding `pad` (an identity tap = pure zero padding), then a stride-2 pad-0 ks x ks conv whose
+    epilogue adds bias / residual and rescales.  `weights(mfma)` returns the packed or direct-layout weights."""
+    if x.C % 4 == 0 and x.C >= 8 and ks == 3 and x.H % 2 == 0 and x.W % 2 == 0:
+        # matrix-core path: the stride-2 pad-0 conv of the padded (H+1)x(W+1) image is the odd-position subset
+        # of the stride-1 pad-1 conv (4x the MFMA work, still ~5x faster than the direct kernel)
+        xf, _ = ops.fir_nhwc(x, kk, 1, 1, pad)
+        return ops.conv(xf, weights(True), 3, cout, mfma=True, bias=bias, res=res, out_scale=out_scale, out=out, sub2=True)
+    if x.C % 4 == 0:
+        xf, _ = ops.fir_nhwc(x, kk, 1, 1, pad)
+    else:   # image pyramid with few channels: planes kernel
+        assert x.ld == x.C
+        t = x.base.reshape(x.B, x.H, x.W, x.C)
+        planes = t.reshape(x.B, 1, x.H, x.W) if x.C == 1 else t.permute(0, 3, 1, 2).contiguous()
+        xf = View.from_nchw(upfirdn2d(planes, _device_kernel(np.ascontiguousarray(kk, np.float32), x.device), pad=pad))
+    return ops.conv(xf, weights(False), ks, cout, mfma=False, stride=2, pad=0, bias=bias, res=res, out_scale=out_scale, out=out)
 
 
 class Conv2d(nn.Module):
@@ -107,20 +146,7 @@ class Conv2d(nn.Module):
         if not self.down:
             return ops.conv(x, self._weights(), self.kernel, self.weight.shape[0], mfma=False, bias=bias, res=res, out_scale=out_scale, out=out)
         kk, up, down, pad = fir_params('conv_down', self.resample_kernel, conv_k=self.kernel)
-        if x.C % 4 == 0 and x.C >= 8 and self.kernel == 3 and x.H % 2 == 0 and x.W % 2 == 0:
-            # matrix-core path: the stride-2 pad-0 conv of the FIR'd (H+1)x(W+1) image is the odd-position subset
-            # of the stride-1 pad-1 conv (4x the MFMA work, still ~5x faster than the direct kernel)
-            xf, _ = ops.fir_nhwc(x, kk, up, down, pad)
-            return ops.conv(xf, self._weights(mfma=True), 3, self.weight.shape[0], mfma=True, bias=bias, res=res, out_scale=out_scale,
-                            out=out, sub2=True)
-        if x.C % 4 == 0:
-            xf, _ = ops.fir_nhwc(x, kk, up, down, pad)
-        else:   # single-channel image pyramid: NHWC == planes
-            assert x.C == 1 and x.ld == 1
-            t = upfirdn2d(x.base.reshape(x.B, 1, x.H, x.W), _device_kernel(kk, x.device), pad=pad)
-            xf = View(t, x.B, t.shape[2], t.shape[3], 1)
-        return ops.conv(xf, self._weights(), self.kernel, self.weight.shape[0], mfma=False, stride=2, pad=0, bias=bias, res=res,
-                        out_scale=out_scale, out=out)
+        return padded_strided_conv(x, kk, pad, self._weights, self.kernel, self.weight.shape[0], bias, res, out_scale, out)
 
     def forward(self, x):
         return self.run(View.from_nchw(x)).to_nchw()

@@ -129,6 +129,27 @@ extern "C" int mud_timestep_embedding(const int64_t* t, float* out, int B, int d
   return MUD_OK;
 }
 
+// Gaussian Fourier features of log(sigma) (reference layerspp.py:68-77 applied to torch.log(time_cond),
+// ncsnpp_generator_adagn_feat.py:288-289): x_proj = ((log(t) * W[k]) * 2) * pi in fp32, out = [sin | cos].
+__global__ void k_fourier_embedding(const float* __restrict__ t, const float* __restrict__ W, float* __restrict__ out, int B, int n) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  const int b = i / n, k = i % n;
+  const float arg = ((logf(t[b]) * W[k]) * 2.0f) * 3.14159265358979323846f;
+  out[(int64_t)b * 2 * n + k] = sinf(arg);
+  out[(int64_t)b * 2 * n + n + k] = cosf(arg);
+}
+
+extern "C" int mud_fourier_embedding(const float* t, const float* W, float* out, int B, int n, void* stream) {
+  MUD_REQUIRE(B >= 0 && n > 0, "mud_fourier_embedding: bad sizes");
+  if (B == 0) return MUD_OK;
+  MUD_REQUIRE(t && W && out, "mud_fourier_embedding: null pointer");
+  hipLaunchKernelGGL(k_fourier_embedding, dim3(mud_cdiv((int64_t)B * n, 256)), dim3(256), 0, (hipStream_t)stream, t, W, out, B, n);
+  MUD_CHECK_LAUNCH("mud_fourier_embedding");
+  return MUD_OK;
+}
+
 __global__ __launch_bounds__(64) void k_pixel_norm(const float* __restrict__ z, float* __restrict__ out, int K) {
   const int b = blockIdx.x, lane = threadIdx.x;
   float ss = 0.f;

@@ -67,6 +67,7 @@ _SIGNATURES = {
     'mud_softmax_rows': (_I, [_P, _L, _I, _I, _P]),
     'mud_mul': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
     'mud_gate_mix': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _L, _I, _P, _I, _P]),
+    'mud_fourier_embedding': (_I, [_P, _P, _P, _I, _I, _P]),
     'mud_resize_bilinear': (_I, [_P, _L, _I, _I, _I, _I, _P, _P]),
     'mud_affine_clamp': (_I, [_P, _L, _F, _F, _F, _F, _P, _P]),
 }

@@ -167,6 +167,15 @@ def timestep_embedding(t, dim, max_positions=10000.0):
     return out
 
 
+def fourier_embedding(t, W):
+    """[sin | cos](2*pi*W*log(t)) -> [B, 2*len(W)] (GaussianFourierProjection of log(time_cond))."""
+    require_gpu(t, W)
+    tf, Wf = _f32(t.float().contiguous()), _f32(W.detach().float().contiguous())
+    out = torch.empty(tf.shape[0], 2 * Wf.shape[0], device=t.device, dtype=torch.float32)
+    _launch('fourier_embedding', load().mud_fourier_embedding, ptr(tf), ptr(Wf), ptr(out), tf.shape[0], Wf.shape[0], stream_ptr())
+    return out
+
+
 def pixel_norm(z):
     require_gpu(z)
     z = _f32(z.contiguous())

@@ -53,14 +53,14 @@ def default_config(**overrides):
 
 
 def _check_supported(cfg):
-    # The oracle restates the default-config family only (SURVEY.md section 8 scope); the
-    # alternative block types are row (f4) "next".
-    assert cfg.resblock_type.lower() == 'biggan'
-    assert cfg.progressive.lower() == 'none'
-    assert cfg.progressive_input.lower() == 'residual'
-    assert cfg.embedding_type.lower() == 'positional'
-    assert cfg.conditional and cfg.fir and cfg.resamp_with_conv
+    """What the reference itself can build and run (probed by tests/golden/make_golden.py::golden_variants)."""
+    assert cfg.resblock_type.lower() == 'biggan', "the reference's own constructor fails for 'ddpm' / 'biggan_oneadagn'"
+    assert cfg.progressive.lower() in ('none', 'output_skip'), "progressive='residual' fails inside the reference"
+    assert cfg.progressive_input.lower() in ('residual', 'input_skip', 'none')
+    assert cfg.progressive_combine.lower() in ('sum', 'cat')
+    assert cfg.embedding_type.lower() in ('positional', 'fourier')
     assert list(cfg.fir_kernel) == [1, 3, 3, 1]
+    assert cfg.fir or cfg.progressive.lower() == 'none', "Upsample(fir=False) raises in the reference (layerspp.py:164)"
 
 
 # --------------------------------------------------------------------------------------
@@ -255,17 +255,29 @@ def nin(sd, p, x):
     return torch.einsum('bchw,cd->bdhw', x, sd[p + '.W']) + sd[p + '.b'][None, :, None, None]
 
 
-def resblock(sd, p, x, temb, zemb, up=False, down=False, skip_rescale=True):
+def naive_upsample_2d(x, factor=2):
+    """backbones/up_or_down_sampling.py:64-68: nearest-neighbour repeat."""
+    return x.repeat_interleave(factor, dim=2).repeat_interleave(factor, dim=3)
+
+
+def naive_downsample_2d(x, factor=2):
+    """backbones/up_or_down_sampling.py:71-74: mean over factor x factor boxes."""
+    n, c, h, w = x.shape
+    return x.reshape(n, c, h // factor, factor, w // factor, factor).mean(dim=(3, 5))
+
+
+def resblock(sd, p, x, temb, zemb, up=False, down=False, skip_rescale=True, fir=True):
     """ResnetBlockBigGANpp_Adagn.forward, backbones/layerspp.py:292-324."""
     in_ch = x.shape[1]
     out_ch = sd[p + '.Conv_0.weight'].shape[0]
     h = F.silu(adagn(sd, p + '.GroupNorm_0', x, zemb))
     if up:
-        h, x = upsample_2d(h), upsample_2d(x)
+        h, x = (upsample_2d(h), upsample_2d(x)) if fir else (naive_upsample_2d(h), naive_upsample_2d(x))
     elif down:
-        h, x = downsample_2d(h), downsample_2d(x)
+        h, x = (downsample_2d(h), downsample_2d(x)) if fir else (naive_downsample_2d(h), naive_downsample_2d(x))
     h = _conv(sd, p + '.Conv_0', h)
-    h = h + _lin(sd, p + '.Dense_0', F.silu(temb))[:, :, None, None]
+    if temb is not None:
+        h = h + _lin(sd, p + '.Dense_0', F.silu(temb))[:, :, None, None]
     h = F.silu(adagn(sd, p + '.GroupNorm_1', h, zemb))
     h = _conv(sd, p + '.Conv_1', h)
     if in_ch != out_ch or up or down:
@@ -307,32 +319,72 @@ def conv_block_gap(sd, p, x):
     return _lin(sd, p + '.fc', h.mean(dim=(2, 3)))
 
 
-def pyramid_downsample(sd, p, x):
-    """Downsample(fir, with_conv) -> up_or_down_sampling.Conv2d(down=True),
-    backbones/layerspp.py:196-210, backbones/up_or_down_sampling.py:50-61."""
-    return conv_downsample_2d(x, sd[p + '.Conv2d_0.weight']) + sd[p + '.Conv2d_0.bias'].reshape(1, -1, 1, 1)
+def pyramid_downsample(sd, p, x, fir=True):
+    """Downsample(fir, with_conv=True): FIR + strided conv (up_or_down_sampling.Conv2d(down=True), layerspp.py:196-210,
+    up_or_down_sampling.py:50-61) or, with fir=False, zero-pad right/bottom by one and a stride-2 pad-0 conv (:199-202)."""
+    if fir:
+        return conv_downsample_2d(x, sd[p + '.Conv2d_0.weight']) + sd[p + '.Conv2d_0.bias'].reshape(1, -1, 1, 1)
+    return F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[p + '.Conv_0.weight'], sd[p + '.Conv_0.bias'], stride=2, padding=0)
+
+
+def plain_downsample(x, fir=True):
+    """Downsample(with_conv=False) (layerspp.py:203-207): FIR /2 or 2x2 average pooling."""
+    return downsample_2d(x) if fir else F.avg_pool2d(x, 2, stride=2)
+
+
+def plain_upsample(x, fir=True):
+    """Upsample(with_conv=False, fir=True) (layerspp.py:167-169).  The fir=False branch of the reference (:164) passes
+    'nearest' as F.interpolate's scale_factor and raises, so progressive='output_skip' exists with fir=True only."""
+    assert fir, "Upsample(fir=False) raises in the reference (layerspp.py:164)"
+    return upsample_2d(x)
+
+
+def combine(sd, p, x, y, method):
+    """Combine.forward (layerspp.py:80-95): conv1x1 of the image pyramid, then sum or channel concat."""
+    h = _conv(sd, p + '.Conv_0', x, padding=0)
+    return torch.cat([h, y], dim=1) if method == 'cat' else h + y
+
+
+def fourier_embedding(sd, p, x):
+    """GaussianFourierProjection.forward (layerspp.py:75-77) of log(time_cond) (ncsnpp_generator_adagn_feat.py:288-289)."""
+    x_proj = torch.log(x)[:, None] * sd[p + '.W'][None, :] * 2 * np.pi
+    return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
 
 
 # --------------------------------------------------------------------------------------
 # L2: generator layout + forward
 # --------------------------------------------------------------------------------------
-def build_plan(cfg, which):
-    """Walks the reference constructors (backbones/ncsnpp_generator_adagn_feat.py:171-269 for
-    G1, :572-684 for G2) and returns the ordered module list as dicts."""
+def build_plan(cfg, which, n_cond=3):
+    """Walks the reference constructors (backbones/ncsnpp_generator_adagn_feat.py:86-269 for G1, :486-684 for G2;
+    n_cond=2: the two-condition twins in ncsnpp_generator_adagn_feat_healthy.py) and returns the ordered module list as
+    dicts.  Covers every configuration the reference itself can construct and run (tests/golden/make_golden.py probes
+    them): embedding_type positional|fourier, conditional, progressive none|output_skip, progressive_input
+    residual|input_skip(sum|cat)|none, fir True|False, skip_rescale, any nf / ch_mult / num_res_blocks / attn_resolutions.
+    resblock_type 'ddpm' / 'biggan_oneadagn' and progressive='residual' raise inside the reference's own constructor /
+    forward (UnboundLocalError at :180 / ValueError in its Conv2d(up=True)), so there is nothing to restate."""
     _check_supported(cfg)
     nf, ch_mult, nrb = cfg.num_channels_dae, list(cfg.ch_mult), cfg.num_res_blocks
     nres = len(ch_mult)
     res = [cfg.image_size // (2 ** i) for i in range(nres)]
     attn_res = tuple(int(a) for a in cfg.attn_resolutions)
-    mods = [dict(kind='linear', cin=nf, cout=nf * 4), dict(kind='linear', cin=nf * 4, cout=nf * 4)]
+    prog, pin, comb = cfg.progressive.lower(), cfg.progressive_input.lower(), cfg.progressive_combine.lower()
+    mods = []
+    embed_dim = nf
+    if cfg.embedding_type.lower() == 'fourier':
+        mods.append(dict(kind='fourier', n=nf))
+        embed_dim = 2 * nf
+    if cfg.conditional:
+        mods += [dict(kind='linear', cin=embed_dim, cout=nf * 4), dict(kind='linear', cin=nf * 4, cout=nf * 4)]
     ch = cfg.num_channels
     if which == 'g1':
-        mods += [dict(kind='feat', cin=ch, cout=nf) for _ in range(4)]
+        mods += [dict(kind='feat', cin=ch, cout=nf) for _ in range(1 + n_cond)]
+        head_c = nf * (1 + n_cond)
     else:
         mods += [dict(kind='gap', cin=ch, cout=nf), dict(kind='feat', cin=ch, cout=nf)]
-        mods += [dict(kind='ada', cin=ch, cout=nf) for _ in range(3)]
-    hs_c = [nf * 4]
-    in_ch = nf * 4
+        mods += [dict(kind='ada', cin=ch, cout=nf) for _ in range(n_cond)]
+        head_c = nf * (4 if n_cond == 3 else 2)
+    hs_c = [head_c]
+    in_ch = head_c
     pyr_ch = ch
     for lvl in range(nres):
         for _ in range(nrb):
@@ -344,8 +396,13 @@ def build_plan(cfg, which):
             hs_c.append(in_ch)
         if lvl != nres - 1:
             mods.append(dict(kind='res', cin=in_ch, cout=in_ch, up=False, down=True, stage='downsample', level=lvl))
-            mods.append(dict(kind='pyr', cin=pyr_ch, cout=in_ch))
-            pyr_ch = in_ch
+            if pin == 'input_skip':
+                mods.append(dict(kind='combine', cin=pyr_ch, cout=in_ch, method=comb))
+                if comb == 'cat':
+                    in_ch *= 2
+            elif pin == 'residual':
+                mods.append(dict(kind='pyr', cin=pyr_ch, cout=in_ch))
+                pyr_ch = in_ch
             hs_c.append(in_ch)
     in_ch = hs_c[-1]
     mods.append(dict(kind='res', cin=in_ch, cout=in_ch, up=False, down=False, stage='mid'))
@@ -358,29 +415,34 @@ def build_plan(cfg, which):
             in_ch = out_ch
         if res[lvl] in attn_res:
             mods.append(dict(kind='attn', c=in_ch, stage='up'))
+        if prog == 'output_skip':
+            mods.append(dict(kind='gn', c=in_ch, stage='pyramid', first=(lvl == nres - 1)))
+            mods.append(dict(kind='conv', cin=in_ch, cout=ch, stage='pyramid'))
         if lvl != 0:
             mods.append(dict(kind='res', cin=in_ch, cout=in_ch, up=True, down=False, stage='upsample', level=lvl))
     assert not hs_c
-    mods.append(dict(kind='gn', c=in_ch))
-    mods.append(dict(kind='conv', cin=in_ch, cout=ch))
+    if prog != 'output_skip':
+        mods.append(dict(kind='gn', c=in_ch, stage='tail'))
+        mods.append(dict(kind='conv', cin=in_ch, cout=ch, stage='tail'))
     for i, m in enumerate(mods):
         m['idx'] = i
     return mods
 
 
-def param_spec(cfg, which):
-    """name -> shape, in the reference's state_dict() order (checked against the reference in
-    oracle/validate_against_reference.py)."""
+def param_spec(cfg, which, n_cond=3):
+    """name -> shape, in the reference's state_dict() order (checked against the reference's own modules by
+    tests/golden/make_golden.py for every configuration it records)."""
     spec = OrderedDict()
     zd = cfg.z_emb_dim
     nf = cfg.num_channels_dae
     if which == 'g2':
-        for n in ('feat_weight_c1', 'feat_weight_c2', 'feat_weight_c3'):
+        pairs = ('c12', 'c23', 'c31') if n_cond == 3 else ('c12',)
+        for n in ('feat_weight_c1', 'feat_weight_c2', 'feat_weight_c3')[:len(pairs)]:
             spec[n + '.weight'] = (nf, nf, 3, 3)
             spec[n + '.bias'] = (nf,)
-        for pair in ('c12', 'c23', 'c31'):
+        for pair in pairs:
             for a in ('feat_att1_', 'feat_att2_'):
-                spec[a + pair + '.weight'] = (nf, 3 * nf, 3, 3)
+                spec[a + pair + '.weight'] = (nf, n_cond * nf, 3, 3)
                 spec[a + pair + '.bias'] = (nf,)
 
     def conv(p, cin, cout, k=3):
@@ -391,10 +453,12 @@ def param_spec(cfg, which):
         spec[p + '.weight'] = (cout, cin)
         spec[p + '.bias'] = (cout,)
 
-    for m in build_plan(cfg, which):
+    for m in build_plan(cfg, which, n_cond):
         p = f"all_modules.{m['idx']}"
         k = m['kind']
-        if k == 'linear':
+        if k == 'fourier':
+            spec[p + '.W'] = (m['n'],)
+        elif k == 'linear':
             lin(p, m['cin'], m['cout'])
         elif k in ('feat', 'gap', 'ada'):
             conv(p + '.conv1', m['cin'], m['cout'])
@@ -417,8 +481,10 @@ def param_spec(cfg, which):
             for i in range(4):
                 spec[p + f'.NIN_{i}.W'] = (m['c'], m['c'])
                 spec[p + f'.NIN_{i}.b'] = (m['c'],)
-        elif k == 'pyr':
-            conv(p + '.Conv2d_0', m['cin'], m['cout'])
+        elif k == 'pyr':     # Downsample(with_conv=True): FIR form holds Conv2d_0, the naive form Conv_0 (layerspp.py:181-191)
+            conv(p + ('.Conv2d_0' if cfg.fir else '.Conv_0'), m['cin'], m['cout'])
+        elif k == 'combine':
+            conv(p + '.Conv_0', m['cin'], m['cout'], k=1)
         elif k == 'gn':
             spec[p + '.weight'] = (m['c'],)
             spec[p + '.bias'] = (m['c'],)
@@ -430,13 +496,13 @@ def param_spec(cfg, which):
     return spec
 
 
-def make_state_dict(cfg, which, seed=1234):
+def make_state_dict(cfg, which, seed=1234, n_cond=3):
     """Weights-from-seed scheme owned by the build: every tensor is
     drawn from its own CPU generator keyed by (seed, which, name), at fan-avg scale 1 - including
     the tensors the reference initialises with init_scale=0 (Conv_1, NIN_3, final conv), which
     would otherwise make every parity check vacuous - biases are perturbed, norm gains ~1."""
     sd = OrderedDict()
-    for name, shape in param_spec(cfg, which).items():
+    for name, shape in param_spec(cfg, which, n_cond).items():
         g = torch.Generator().manual_seed((zlib.crc32(f'{which}:{name}'.encode()) + 7919 * seed) % (2 ** 31))
         if len(shape) >= 2:
             rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
@@ -445,7 +511,9 @@ def make_state_dict(cfg, which, seed=1234):
             t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * bound
         else:
             t = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
-            if name.endswith('style.bias'):
+            if name.endswith('.W'):                # GaussianFourierProjection: randn * scale (layerspp.py:73)
+                t = t * (10.0 * cfg.fourier_scale)
+            elif name.endswith('style.bias'):
                 t[: shape[0] // 2] += 1.0          # gamma half (layerspp.py:44)
             elif name.endswith('.weight'):
                 t += 1.0                           # GroupNorm affine gain
@@ -455,9 +523,11 @@ def make_state_dict(cfg, which, seed=1234):
 
 def _trunk(sd, cfg, plan, start, hs0, x_in, temb, zemb):
     """Shared down/mid/up trunk, backbones/ncsnpp_generator_adagn_feat.py:335-447."""
-    sr = cfg.skip_rescale
+    sr, fir = cfg.skip_rescale, cfg.fir
+    pin = cfg.progressive_input.lower()
     hs = [hs0]
-    pyr = x_in
+    pyr = x_in if pin != 'none' else None
+    out_pyr = None                      # progressive='output_skip' image pyramid (:389-417)
     i = start
     n = len(plan)
     h = None
@@ -466,26 +536,37 @@ def _trunk(sd, cfg, plan, start, hs0, x_in, temb, zemb):
         p = f"all_modules.{m['idx']}"
         k = m['kind']
         if k == 'res' and m['stage'] == 'down':
-            h = resblock(sd, p, hs[-1], temb, zemb, skip_rescale=sr)
+            h = resblock(sd, p, hs[-1], temb, zemb, skip_rescale=sr, fir=fir)
             if plan[i + 1]['kind'] == 'attn' and plan[i + 1]['stage'] == 'down':
                 i += 1
                 h = attn_block(sd, f"all_modules.{plan[i]['idx']}", h, sr)
             hs.append(h)
         elif k == 'res' and m['stage'] == 'downsample':
-            h = resblock(sd, p, hs[-1], temb, zemb, down=True, skip_rescale=sr)
-            i += 1
-            pyr = pyramid_downsample(sd, f"all_modules.{plan[i]['idx']}", pyr)
-            pyr = (pyr + h) / SQRT2 if sr else pyr + h
-            h = pyr
+            h = resblock(sd, p, hs[-1], temb, zemb, down=True, skip_rescale=sr, fir=fir)
+            if pin == 'input_skip':
+                i += 1
+                pyr = plain_downsample(pyr, fir)
+                h = combine(sd, f"all_modules.{plan[i]['idx']}", pyr, h, plan[i]['method'])
+            elif pin == 'residual':
+                i += 1
+                pyr = pyramid_downsample(sd, f"all_modules.{plan[i]['idx']}", pyr, fir)
+                pyr = (pyr + h) / SQRT2 if sr else pyr + h
+                h = pyr
             hs.append(h)
         elif k == 'res' and m['stage'] == 'mid':
-            h = resblock(sd, p, h, temb, zemb, skip_rescale=sr)   # first one: h is hs[-1] (:370)
+            h = resblock(sd, p, h, temb, zemb, skip_rescale=sr, fir=fir)   # first one: h is hs[-1] (:370)
         elif k == 'attn':
             h = attn_block(sd, p, h, sr)
         elif k == 'res' and m['stage'] == 'up':
-            h = resblock(sd, p, torch.cat([h, hs.pop()], dim=1), temb, zemb, skip_rescale=sr)
+            h = resblock(sd, p, torch.cat([h, hs.pop()], dim=1), temb, zemb, skip_rescale=sr, fir=fir)
         elif k == 'res' and m['stage'] == 'upsample':
-            h = resblock(sd, p, h, temb, zemb, up=True, skip_rescale=sr)
+            h = resblock(sd, p, h, temb, zemb, up=True, skip_rescale=sr, fir=fir)
+        elif k == 'gn' and m['stage'] == 'pyramid':
+            c = h.shape[1]
+            ph = F.silu(F.group_norm(h, _groups(c), sd[p + '.weight'], sd[p + '.bias'], eps=1e-6))
+            i += 1
+            ph = _conv(sd, f"all_modules.{plan[i]['idx']}", ph)
+            out_pyr = ph if m['first'] else plain_upsample(out_pyr, fir) + ph
         elif k == 'gn':
             assert not hs
             c = h.shape[1]
@@ -495,39 +576,50 @@ def _trunk(sd, cfg, plan, start, hs0, x_in, temb, zemb):
         else:
             raise AssertionError(m)
         i += 1
+    if cfg.progressive.lower() == 'output_skip':
+        h = out_pyr
     return h if cfg.not_use_tanh else torch.tanh(h)
 
 
 def _embeddings(sd, cfg, t, z):
     zemb = z_transform(sd, z, cfg.n_mlp)
-    temb = timestep_embedding(t, cfg.num_channels_dae)
-    temb = _lin(sd, 'all_modules.0', temb)
-    temb = _lin(sd, 'all_modules.1', F.silu(temb))
-    return temb, zemb
+    i = 0
+    if cfg.embedding_type.lower() == 'fourier':
+        temb = fourier_embedding(sd, 'all_modules.0', t)
+        i = 1
+    else:
+        temb = timestep_embedding(t, cfg.num_channels_dae)
+    if not cfg.conditional:
+        return None, zemb, i
+    temb = _lin(sd, f'all_modules.{i}', temb)
+    temb = _lin(sd, f'all_modules.{i + 1}', F.silu(temb))
+    return temb, zemb, i + 2
 
 
 def g1_forward(sd, cfg, x, c1, c2, c3, t, z):
-    """NCSNpp.forward, backbones/ncsnpp_generator_adagn_feat.py:279-447."""
-    plan = build_plan(cfg, 'g1')
-    temb, zemb = _embeddings(sd, cfg, t, z)
+    """NCSNpp.forward, backbones/ncsnpp_generator_adagn_feat.py:279-447 (c3=None: the two-condition variant,
+    ncsnpp_generator_adagn_feat_healthy.py:279-445)."""
+    conds = (c1, c2) if c3 is None else (c1, c2, c3)
+    plan = build_plan(cfg, 'g1', len(conds))
+    temb, zemb, m0 = _embeddings(sd, cfg, t, z)
     if not cfg.centered:
         x = 2 * x - 1.0
-    feats = [conv_feat_block(sd, f'all_modules.{2 + j}', v) for j, v in enumerate((x, c1, c2, c3))]
-    return _trunk(sd, cfg, plan, 6, torch.cat(feats, dim=1), x, temb, zemb)
+    feats = [conv_feat_block(sd, f'all_modules.{m0 + j}', v) for j, v in enumerate((x,) + conds)]
+    return _trunk(sd, cfg, plan, m0 + len(feats), torch.cat(feats, dim=1), x, temb, zemb)
 
 
 def g2_forward(sd, cfg, x, c1, c2, c3, t, z, pseudo_target):
-    """NCSNpp_adaptive.forward, backbones/ncsnpp_generator_adagn_feat.py:694-905."""
-    plan = build_plan(cfg, 'g2')
-    temb, zemb = _embeddings(sd, cfg, t, z)
+    """NCSNpp_adaptive.forward, backbones/ncsnpp_generator_adagn_feat.py:694-905 (c3=None: the two-condition variant,
+    ncsnpp_generator_adagn_feat_healthy.py:693-873, one fused pair)."""
+    conds = (c1, c2) if c3 is None else (c1, c2, c3)
+    plan = build_plan(cfg, 'g2', len(conds))
+    temb, zemb, m0 = _embeddings(sd, cfg, t, z)
     if not cfg.centered:
         x = 2 * x - 1.0
-    style = conv_block_gap(sd, 'all_modules.2', pseudo_target)
-    xf = conv_feat_block(sd, 'all_modules.3', x)
-    f1 = conv_block(sd, 'all_modules.4', c1, style)
-    f2 = conv_block(sd, 'all_modules.5', c2, style)
-    f3 = conv_block(sd, 'all_modules.6', c3, style)
-    cat = torch.cat((f1, f2, f3), dim=1)
+    style = conv_block_gap(sd, f'all_modules.{m0}', pseudo_target)
+    xf = conv_feat_block(sd, f'all_modules.{m0 + 1}', x)
+    f = [conv_block(sd, f'all_modules.{m0 + 2 + j}', c, style) for j, c in enumerate(conds)]
+    cat = torch.cat(f, dim=1)
 
     def gate(name):
         return torch.sigmoid(_conv(sd, name, cat))
@@ -537,10 +629,10 @@ def g2_forward(sd, cfg, x, c1, c2, c3, t, z, pseudo_target):
         att = _conv(sd, wname, g1 * fa)
         return g2 * att + (1 - g2) * fb
 
-    f12 = fuse('c12', 'feat_weight_c1', f1, f2)
-    f23 = fuse('c23', 'feat_weight_c2', f2, f3)
-    f31 = fuse('c31', 'feat_weight_c3', f3, f1)
-    return _trunk(sd, cfg, plan, 7, torch.cat((xf, f12, f23, f31), dim=1), x, temb, zemb)
+    fused = [fuse('c12', 'feat_weight_c1', f[0], f[1])]
+    if len(conds) == 3:
+        fused += [fuse('c23', 'feat_weight_c2', f[1], f[2]), fuse('c31', 'feat_weight_c3', f[2], f[0])]
+    return _trunk(sd, cfg, plan, m0 + 2 + len(conds), torch.cat([xf] + fused, dim=1), x, temb, zemb)
 
 
 def sample_from_model(coef, sd1, sd2, cfg, c1, c2, c3, x_init, zs, noises, return_steps=False):

@@ -462,14 +462,102 @@ def golden_volume():
     return out
 
 
+VARIANT_BASE = dict(image_size=32, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(16,), num_res_blocks=1)
+VARIANTS = {     # every alternate configuration the reference itself can construct and run
+    'output_skip': dict(progressive='output_skip'),
+    'input_skip_sum': dict(progressive_input='input_skip', progressive_combine='sum'),
+    'input_skip_cat': dict(progressive_input='input_skip', progressive_combine='cat'),
+    'input_none': dict(progressive_input='none'),
+    'fir_false': dict(fir=False),
+    'fir_false_input_skip': dict(fir=False, progressive_input='input_skip'),
+    'fourier': dict(embedding_type='fourier', fourier_scale=16.0),
+    'unconditional': dict(conditional=False),
+    'no_rescale': dict(skip_rescale=False),
+    'uncentered_notanh': dict(centered=False, not_use_tanh=True),
+    'three_levels_all': dict(ch_mult=[1, 1, 2], attn_resolutions=(8,), progressive='output_skip', progressive_input='input_skip',
+                             progressive_combine='cat', skip_rescale=False),
+    'two_channels': dict(num_channels=2),            # G1 only: the reference's G2 cannot take a 1-channel pseudo-target then
+    'healthy': dict(),                               # ncsnpp_generator_adagn_feat_healthy.py: two conditions
+}
+UNBUILDABLE = {   # recorded for the record: these raise inside the reference, so there is nothing to be compatible with
+    'resblock_ddpm': dict(resblock_type='ddpm'), 'resblock_oneadagn': dict(resblock_type='biggan_oneadagn'),
+    'progressive_residual': dict(progressive='residual'),
+    'fir_false_output_skip': dict(fir=False, progressive='output_skip'),     # Upsample(fir=False): bad F.interpolate call (layerspp.py:164)
+}
+
+
+def golden_variants():
+    print('alternate configurations (row f4): one G1 + G2 forward each, B=2, 32x32')
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        # the two-condition twins register the same model names as the main file, so the reference cannot import both in
+        # one process: empty its registry first (nothing here looks models up by name)
+        from backbones import utils as R_utils
+        R_utils._MODELS.clear()
+        from backbones import ncsnpp_generator_adagn_feat_healthy as R_H
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    for name, kw in UNBUILDABLE.items():
+        cfg = O.default_config(**{**VARIANT_BASE, **kw})
+        for cls in (R_G1, R_G2):
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    m = cls(cfg)
+                    x = torch.randn(2, 1, 32, 32)
+                    m(*([x, x, x, x, torch.tensor([1, 3]), torch.randn(2, cfg.nz)] + ([x] if cls is R_G2 else [])))
+                raise AssertionError(f'{name}: the reference now builds - restate it')
+            except (UnboundLocalError, ValueError) as e:
+                print(f'    {name:22s} {cls.__name__:16s} reference raises {type(e).__name__}: {str(e)[:60]}')
+    for name, kw in VARIANTS.items():
+        cfg = O.default_config(**{**VARIANT_BASE, **kw})
+        nc = 2 if name == 'healthy' else 3
+        C = cfg.num_channels
+        x, c1, c2, c3 = (torch.tanh(torch.randn(2, C, 32, 32, generator=g)) for _ in range(4))
+        if not cfg.centered:
+            x = (x + 1) / 2
+        z = torch.randn(2, cfg.nz, generator=g)
+        t = torch.tensor([0.5, 2.0]) if cfg.embedding_type == 'fourier' else torch.tensor([1, 3])
+        out.update({f'{name}.x': x, f'{name}.c1': c1, f'{name}.c2': c2, f'{name}.c3': c3, f'{name}.z': z, f'{name}.t': t})
+        classes = ((R_H.NCSNpp, R_H.NCSNpp_adaptive) if name == 'healthy' else (R_G1, R_G2))
+        y1 = None
+        for which, cls in zip(('g1', 'g2'), classes):
+            if which == 'g2' and C != 1:
+                continue
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = cls(cfg).eval()
+            sd = O.make_state_dict(cfg, which, 77, n_cond=nc)
+            rsd = m.state_dict()
+            assert list(rsd.keys()) == list(sd.keys()), f'{name}/{which}: state_dict key order differs'
+            assert all(tuple(rsd[k].shape) == tuple(sd[k].shape) for k in sd), f'{name}/{which}: shapes differ'
+            m.load_state_dict(sd, strict=True)
+            conds = [c1, c2] if nc == 2 else [c1, c2, c3]
+            with contextlib.redirect_stdout(io.StringIO()):
+                if which == 'g1':
+                    y = m(x, *conds, t, z); y1 = y
+                    o = O.g1_forward(sd, cfg, x, c1, c2, c3 if nc == 3 else None, t, z)
+                else:
+                    y = m(x, *conds, t, z, y1[:, [0], :])
+                    o = O.g2_forward(sd, cfg, x, c1, c2, c3 if nc == 3 else None, t, z, y1[:, [0], :])
+            check(f'variant.{name}.{which}', o, y, 2e-5)
+            assert float(y.std()) > 0.05
+            out[f'{name}.{which}'] = y
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true', help='validate the oracle only, write nothing')
     ap.add_argument('--skip-full', action='store_true')
     ap.add_argument('--only-cfg5', action='store_true', help='(re)generate full_cfg5.npz alone')
     ap.add_argument('--only-volume', action='store_true', help='(re)generate volume.npz alone')
+    ap.add_argument('--only-variants', action='store_true', help='(re)generate variants.npz alone')
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.only_variants:
+        d = t2n(golden_variants())
+        if not a.check:
+            np.savez_compressed(os.path.join(HERE, 'variants.npz'), **d)
+            print('wrote variants.npz', f'{os.path.getsize(os.path.join(HERE, "variants.npz")) / 1e6:.2f} MB')
+        return
     if a.only_volume:
         d = t2n(golden_volume())
         if not a.check:
@@ -490,6 +578,7 @@ def main():
         'small_models.npz': t2n(golden_small_models()),
         'critic.npz': t2n(golden_discriminator()),
         'volume.npz': t2n(golden_volume()),
+        'variants.npz': t2n(golden_variants()),
     }
     if not a.skip_full:
         u8, full = golden_full()

@@ -55,3 +55,28 @@ SMALL_CFGS = {
 def small_conds(cfg, B=2):
     g = torch.Generator().manual_seed(101)
     return [torch.tanh(torch.randn(B, 1, cfg.image_size, cfg.image_size, generator=g)) for _ in range(3)]
+
+
+# the alternate configurations recorded in tests/golden/variants.npz (same table as
+# tests/golden/make_golden.py::VARIANTS - every configuration the reference itself can construct and run)
+VARIANT_BASE = dict(image_size=32, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(16,), num_res_blocks=1)
+VARIANTS = {
+    'output_skip': dict(progressive='output_skip'),
+    'input_skip_sum': dict(progressive_input='input_skip', progressive_combine='sum'),
+    'input_skip_cat': dict(progressive_input='input_skip', progressive_combine='cat'),
+    'input_none': dict(progressive_input='none'),
+    'fir_false': dict(fir=False),
+    'fir_false_input_skip': dict(fir=False, progressive_input='input_skip'),
+    'fourier': dict(embedding_type='fourier', fourier_scale=16.0),
+    'unconditional': dict(conditional=False),
+    'no_rescale': dict(skip_rescale=False),
+    'uncentered_notanh': dict(centered=False, not_use_tanh=True),
+    'three_levels_all': dict(ch_mult=[1, 1, 2], attn_resolutions=(8,), progressive='output_skip', progressive_input='input_skip',
+                             progressive_combine='cat', skip_rescale=False),
+    'two_channels': dict(num_channels=2),
+    'healthy': dict(),
+}
+UNBUILDABLE = {     # these raise inside the reference's own constructor / forward
+    'resblock_ddpm': dict(resblock_type='ddpm'), 'resblock_oneadagn': dict(resblock_type='biggan_oneadagn'),
+    'progressive_residual': dict(progressive='residual'), 'fir_false_output_skip': dict(fir=False, progressive='output_skip'),
+}

@@ -526,3 +526,52 @@ def test_predict_volume_end_to_end_nifti(tmp_path):
         V.predict_volume(V.build_argparser(big))
     out = V.predict_volume(V.build_argparser(big + ['--resize_back']))
     assert V.read_nifti(out)[0].shape == (16, 16, 9)
+
+
+# ----------------------------------------------------------------------------------------------
+# row f4: alternate configurations
+# ----------------------------------------------------------------------------------------------
+from helpers import VARIANT_BASE, VARIANTS      # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(VARIANTS))
+def test_variant_generators_vs_reference(name):
+    """Every configuration the reference can construct and run (output_skip / input_skip sum|cat / no input pyramid /
+    fir=False resamplers / Fourier time embedding / unconditional / no skip rescale / [0,1] inputs without tanh / two image
+    channels / the two-condition twins): G1 and G2 forward against the reference's own outputs."""
+    gd = load_golden('variants.npz')
+    cfg = O.default_config(**{**VARIANT_BASE, **VARIANTS[name]})
+    if name == 'healthy':
+        from backbones import ncsnpp_generator_adagn_feat_healthy as H
+        G1, G2, nc = H.NCSNpp, H.NCSNpp_adaptive, 2
+    else:
+        *_, G1, G2 = _imports()
+        nc = 3
+    x, c1, c2, t, z = (g(gd[f'{name}.{k}']) for k in ('x', 'c1', 'c2', 't', 'z'))
+    conds = [c1, c2] + ([g(gd[f'{name}.c3'])] if nc == 3 else [])
+    m1 = G1(cfg)
+    m1.load_state_dict(O.make_state_dict(cfg, 'g1', 77, n_cond=nc))
+    y1 = m1.to(DEV).eval()(x, *conds, t, z)
+    e1 = maxdiff(y1, gd[f'{name}.g1'])
+    e2 = 0.0
+    if f'{name}.g2' in gd:
+        m2 = G2(cfg)
+        m2.load_state_dict(O.make_state_dict(cfg, 'g2', 77, n_cond=nc))
+        y2 = m2.to(DEV).eval()(x, *conds, t, z, g(gd[f'{name}.g1'])[:, [0], :].contiguous())
+        e2 = maxdiff(y2, gd[f'{name}.g2'])
+    print(f'variant {name}: max-abs G1 {e1:.2e} G2 {e2:.2e}')
+    assert max(e1, e2) <= 1e-3
+
+
+def test_fourier_embedding_and_naive_resamplers():
+    ops, S, layerspp, ud, *_ = _imports()
+    gen = torch.Generator().manual_seed(3)
+    W = torch.randn(16, generator=gen) * 16.0
+    t = torch.rand(5, generator=gen) * 3 + 0.01
+    xp = torch.log(t)[:, None] * W[None, :] * 2 * np.pi
+    want = torch.cat([torch.sin(xp), torch.cos(xp)], -1)
+    got = ops.fourier_embedding(g(t), g(W))
+    assert maxdiff(got, want) <= 2e-5          # |arg| up to ~500: one ulp of the argument is 3e-5
+    x = torch.randn(2, 3, 6, 10, generator=gen)
+    assert torch.equal(ud.naive_upsample_2d(g(x)).cpu(), O.naive_upsample_2d(x))
+    assert maxdiff(ud.naive_downsample_2d(g(x)), O.naive_downsample_2d(x)) <= 1e-6
