@@ -375,6 +375,44 @@ def golden_full():
     return u8, out
 
 
+def brats_like_slices_u8(n, seed=2019, size=256):
+    """Synthetic BraTS-shaped slices: smooth Gaussian fields inside a head-sized disc, black
+    background, 4 contrasts per slice, quantised to uint8 so that the fixture is exact on every host."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, size), torch.linspace(-1, 1, size), indexing='ij')
+    out = np.zeros((n, 4, size, size), np.uint8)
+    k = torch.tensor([1., 3., 3., 1.]); k = (k[:, None] * k[None, :]) / 64.0
+    for i in range(n):
+        cx, cy, r = (torch.rand(3, generator=g) * torch.tensor([0.2, 0.2, 0.15]) + torch.tensor([-0.1, -0.1, 0.7])).tolist()
+        mask = ((xx - cx) ** 2 + ((yy - cy) / 1.15) ** 2) < r * r
+        base = torch.randn(1, 1, size // 8, size // 8, generator=g)
+        base = torch.nn.functional.interpolate(base, size=(size, size), mode='bilinear', align_corners=False)
+        for c in range(4):
+            f = 0.7 * base + 0.5 * torch.randn(1, 1, size, size, generator=g)
+            for _ in range(3):
+                f = torch.nn.functional.conv2d(torch.nn.functional.pad(f, (2, 1, 2, 1)), k[None, None])
+            f = (f - f[0, 0][mask].mean()) / f[0, 0][mask].std()
+            v = torch.clamp(f[0, 0], -3, 3) / 3
+            v = torch.where(mask, v, torch.full_like(v, -1.0))
+            out[i, c] = torch.round((v + 1) / 2 * 255).to(torch.uint8).numpy()
+    return out
+
+
+def golden_cfg3():
+    print('config 3: BraTS-shaped batch, 256x256, 4 slices x (3 conditions + target), 4 steps (takes a few minutes)')
+    cfg = O.default_config()
+    u8 = brats_like_slices_u8(4)
+    sl = torch.from_numpy(u8.astype(np.float32)) / 255.0 * 2.0 - 1.0
+    conds = [sl[:, c:c + 1].contiguous() for c in range(3)]
+    x_init, zs, noises, steps, o_steps = run_sampler(cfg, 1234, 314, conds, 4)
+    for k, (r, o) in enumerate(zip(steps, o_steps)):
+        for nm, a, b in zip(('x01', 'x02', 'xnew'), o, r):
+            check(f'cfg3.step{k}.{nm}', a, b, 5e-5)
+    out = {'slices_u8': u8, 'final': steps[-1][2].numpy().astype(np.float32)}
+    print(f'    cfg3: final range [{float(steps[-1][2].min()):.3f},{float(steps[-1][2].max()):.3f}]')
+    return out
+
+
 CFG5 = dict(ch_mult=[1, 1, 2, 2, 4], num_timesteps=8, attn_resolutions=(16,))   # BASELINE config 5 (SURVEY.md section 8d, item 5)
 
 
@@ -548,10 +586,17 @@ def main():
     ap.add_argument('--check', action='store_true', help='validate the oracle only, write nothing')
     ap.add_argument('--skip-full', action='store_true')
     ap.add_argument('--only-cfg5', action='store_true', help='(re)generate full_cfg5.npz alone')
+    ap.add_argument('--only-cfg3', action='store_true', help='(re)generate batch_cfg3.npz alone')
     ap.add_argument('--only-volume', action='store_true', help='(re)generate volume.npz alone')
     ap.add_argument('--only-variants', action='store_true', help='(re)generate variants.npz alone')
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.only_cfg3:
+        d = golden_cfg3()
+        if not a.check:
+            np.savez_compressed(os.path.join(HERE, 'batch_cfg3.npz'), **d)
+            print('wrote batch_cfg3.npz', f'{os.path.getsize(os.path.join(HERE, "batch_cfg3.npz")) / 1e6:.2f} MB')
+        return
     if a.only_variants:
         d = t2n(golden_variants())
         if not a.check:
@@ -585,6 +630,7 @@ def main():
         files['demo_inputs_u8.npz'] = u8
         files['full_cfg2.npz'] = full
         files['full_cfg5.npz'] = golden_cfg5()
+        files['batch_cfg3.npz'] = golden_cfg3()
     worst = max(REPORT, key=lambda r: r[1])
     print(f'{len(REPORT)} comparisons, worst: {worst[0]} {worst[1]:.3e}')
     if not a.check:

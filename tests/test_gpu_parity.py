@@ -575,3 +575,31 @@ def test_fourier_embedding_and_naive_resamplers():
     x = torch.randn(2, 3, 6, 10, generator=gen)
     assert torch.equal(ud.naive_upsample_2d(g(x)).cpu(), O.naive_upsample_2d(x))
     assert maxdiff(ud.naive_downsample_2d(g(x)), O.naive_downsample_2d(x)) <= 1e-6
+
+
+def test_config3_brats_shaped_batch32_vs_reference():
+    """BASELINE config 3: a batch of 32 BraTS-shaped 256x256 slices through the captured
+    hipGraph sampler (the batched driver's path).  The reference sampled the 4 distinct synthetic slices of the fixture
+    (B=4); here they fill a batch of 32 eight times over with the same per-slice Gaussian draws, so every replica must
+    reproduce the reference's final image, and PSNR / SSIM against the synthetic target must agree with the reference's to
+    +-0.05 dB / +-0.001."""
+    ops, S, *_ = _imports()
+    gd = load_golden('batch_cfg3.npz')
+    cfg = O.default_config()
+    g1, g2 = _build(cfg)
+    sl = gd['slices_u8'].float() / 255.0 * 2.0 - 1.0                     # [4, 4, 256, 256]: 3 conditions + target
+    rep = lambda t: t.repeat(8, *([1] * (t.dim() - 1)))
+    conds = [g(rep(sl[:, c:c + 1].contiguous())) for c in range(3)]
+    x_init, zs, noises = sampler_inputs(cfg, 4, seed_x=314)
+    sampler = S.GraphSampler(S.Posterior_Coefficients(cfg, DEV), g1, g2, cfg, 32, 256, 256, DEV)
+    out = sampler.sample(*conds, g(rep(x_init)), 4, zs=[g(rep(z)) for z in zs], noises=[g(rep(n)) for n in noises]).cpu()
+    ref = gd['final']
+    err = max(maxdiff(out[r * 4:(r + 1) * 4], ref) for r in range(8))
+    to01 = lambda a: (np.asarray(a, np.float64) + 1) / 2
+    dps, dss = [], []
+    for i in range(4):
+        tgt = to01(sl[i, 3].numpy())
+        dps.append(O.psnr(tgt, to01(out[i, 0].numpy())) - O.psnr(tgt, to01(ref[i, 0].numpy())))
+        dss.append(O.ssim(tgt, to01(out[i, 0].numpy())) - O.ssim(tgt, to01(ref[i, 0].numpy())))
+    print(f'cfg3 B=32: max-abs {err:.2e}, dPSNR {np.mean(dps):+.4f} dB (max {np.abs(dps).max():.4f}), dSSIM {np.mean(dss):+.6f}')
+    assert err <= 1e-3 and np.abs(dps).max() <= 0.05 and np.abs(dss).max() <= 0.001
