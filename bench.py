@@ -7,8 +7,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic slices: the complete 4-step
 dual-generator reverse sampling (4 x [G1 -> G2 -> posterior]) of B 256x256 slices per GPU (BASELINE
-config 2 shapes: nf=64, ch_mult 1-2-4, 2 res blocks, nz=100; weights from the seed scheme - no trained
-weights exist offline; noise drawn on the device).  value = slices/s over ALL ranks = N*B*K / max-over-
+config 2 shapes: nf=64, ch_mult 1-2-4, 2 res blocks, nz=100; random-init weights - no trained weights
+exist offline; noise drawn on the device).  value = slices/s over ALL ranks = N*B*K / max-over-
 ranks wall time, inputs resident in HBM, fp32 in / fp32 out.
 
 One JSON line on rank 0, with
@@ -49,13 +49,55 @@ def parse():
     return ap.parse_args()
 
 
+def bench_config():
+    """BASELINE config 2 (demo.ipynb cell 3 / SURVEY.md section 8): the attribute bag the generators' constructors read."""
+    from types import SimpleNamespace
+    return SimpleNamespace(
+        num_timesteps=4, beta_min=0.1, beta_max=20.0, centered=True, use_geometric=False, num_channels=1, num_channels_dae=64,
+        n_mlp=3, ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=(16,), dropout=0.0, resamp_with_conv=True, conditional=True,
+        fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type='biggan', progressive='none',
+        progressive_input='residual', progressive_combine='sum', embedding_type='positional', fourier_scale=16.0,
+        not_use_tanh=False, image_size=256, nz=100, z_emb_dim=256, t_emb_dim=256)
+
+
+def random_weights_(module, seed):
+    """Random-init weights of the architecture (there are no trained weights offline).  MUDIFF_BENCH_WEIGHTS=uniform
+    (default): every matrix / filter U(+-sqrt(3/fan_avg)) (the reference's default_init at scale 1, applied to ALL tensors -
+    including Conv_1, NIN_3 and the output conv that the reference starts at ~0, which would make half the network
+    multiply by zero), biases 0.1*N(0,1), norm gains 1 + 0.1*N(0,1).  =ctor: the constructors' own initialisers with only
+    the ~0 tensors re-drawn."""
+    import math
+    mode = os.environ.get('MUDIFF_BENCH_WEIGHTS', 'uniform')
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() >= 2:
+                if mode == 'ctor' and float(p.abs().max()) >= 1e-6:
+                    continue
+                rf = p[0][0].numel() if p.dim() > 2 else 1
+                bound = math.sqrt(3.0 / ((p.shape[0] + p.shape[1]) * rf / 2.0))
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+            elif mode == 'ctor':
+                if float(p.abs().max()) == 0.0:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith('.W'):
+                continue                                            # Fourier frequencies keep their own scale
+            else:
+                t = 0.1 * torch.randn(p.shape, generator=g)
+                if name.endswith('style.bias'):
+                    t[:p.shape[0] // 2] += 1.0                      # AdaGN gamma half
+                elif name.endswith('.weight'):
+                    t += 1.0                                        # GroupNorm gains
+                p.copy_(t)
+
+
 def build_models(cfg, dev, rank, world):
-    from oracle import mudiff_oracle as O      # weights-from-seed scheme only (no oracle arithmetic here)
     from backbones.ncsnpp_generator_adagn_feat import NCSNpp, NCSNpp_adaptive
+    torch.manual_seed(1234 + rank)
     g1, g2 = NCSNpp(cfg), NCSNpp_adaptive(cfg)
     if rank == 0:
-        g1.load_state_dict(O.make_state_dict(cfg, 'g1', 1234))
-        g2.load_state_dict(O.make_state_dict(cfg, 'g2', 1234))
+        random_weights_(g1, 1)
+        random_weights_(g2, 2)
     g1, g2 = g1.to(dev).eval(), g2.to(dev).eval()
     if world > 1:
         # parameters live on rank 0 (checkpoint reader); one flattened RCCL broadcast per generator over xGMI
@@ -134,9 +176,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)   # nccl == RCCL on ROCm
 
-    from oracle import mudiff_oracle as O
     from mudiff_hip import ops, sampling as S
-    cfg = O.default_config()
+    cfg = bench_config()
     B, K, W = a.batch, a.steps, a.warmup
     H = cfg.image_size
     g1, g2 = build_models(cfg, dev, rank, world)
