@@ -425,6 +425,40 @@ def test_cpu_tensors_fail_loudly():
         m(z, z, z, z, torch.zeros(1, dtype=torch.int64), torch.zeros(1, cfg.nz))
 
 
+def test_c_abi_rejects_bad_arguments_without_launching():
+    """The C entry points validate on the host before any launch (a faulting kernel can reset the device): null
+    pointers, misaligned / too-narrow views, unsupported sizes return MUD_ERR_* with a message in mud_last_error(), and
+    the Python layer turns them into MudiffHipError (a RuntimeError, like the reference's TORCH_CHECK failures)."""
+    import ctypes
+    import mudiff_hip
+    ops, *_ = _imports()
+    lib = mudiff_hip.load()
+    x = torch.zeros(1, 8, 8, 16, device=DEV)
+    out = torch.zeros(1, 8, 8, 16, device=DEV)
+    k = torch.ones(4, 4, device=DEV)
+    # upfirdn2d: null input, zero-sized output, oversized filter
+    assert lib.mud_upfirdn2d(None, 1, 8, 8, k.data_ptr(), 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, out.data_ptr(), None) == 1
+    assert b'null' in lib.mud_last_error()
+    assert lib.mud_upfirdn2d(x.data_ptr(), 1, 2, 2, k.data_ptr(), 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, out.data_ptr(), None) == 1
+    assert lib.mud_upfirdn2d(x.data_ptr(), 1, 8, 8, k.data_ptr(), 9, 9, 1, 1, 1, 1, 4, 4, 4, 4, out.data_ptr(), None) == 1
+    # attention: unsupported head dim is reported, not launched
+    assert lib.mud_attention_supported(24) == 0 and lib.mud_attention_supported(256) == 1
+    assert lib.mud_attention(x.data_ptr(), 1, 64, 24, 72, ctypes.c_float(1.0), out.data_ptr(), 24, None) != 0
+    # conv: channel pitch smaller than the channel count, misaligned base pointer
+    xv = ops.View(x, 1, 8, 8, 16)
+    w = ops.pack_conv_weight(torch.zeros(64, 16, 3, 3, device=DEV))
+    bad = ops.View(x, 1, 8, 8, 16)
+    bad.ld = 8
+    with pytest.raises(mudiff_hip.MudiffHipError):
+        ops.conv(bad, w, 3, 64, mfma=True)
+    with pytest.raises(mudiff_hip.MudiffHipError):
+        ops.fir_nhwc(ops.View(torch.zeros(1, 4, 4, 6, device=DEV), 1, 4, 4, 6), [[1.0]], 1, 1, (0, 0))      # C % 4 != 0
+    with pytest.raises(mudiff_hip.MudiffHipError):
+        ops.resize_bilinear(torch.zeros(1, 1, 4, 4, device=DEV), (0, 4))
+    torch.cuda.synchronize()
+    assert float(ops.conv(xv, w, 3, 64, mfma=True).tensor().abs().max()) == 0.0      # the library still works afterwards
+
+
 # ----------------------------------------------------------------------------------------------
 # rows f1 (uncertainty map) and f3 (volume pipeline)
 # ----------------------------------------------------------------------------------------------
