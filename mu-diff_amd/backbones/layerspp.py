@@ -38,8 +38,8 @@ def _groups(c):
 
 def use_mfma(cin, cout):
     """Matrix-core implicit GEMM unless C_in is too small to feed it (the C_in == 1 head convolutions are
-    pure store streams): those go to the exact direct kernel.  The C_out == 1 tail also runs on the
-    matrix cores (one 64-wide channel tile, 63 columns idle): 5x faster than one thread per pixel."""
+    pure store streams): those go to the exact direct kernel (as do the C_out <= 4 image-space output convs, which
+    have their own LDS-tiled kernel there: ConvParam)."""
     return cin % 4 == 0 and cin >= 8
 
 
@@ -71,7 +71,9 @@ class ConvParam:
     def __init__(self, conv: nn.Conv2d):
         w = conv.weight.detach()
         self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
-        self.mfma = use_mfma(self.cin, self.cout) and self.ks in (1, 3)
+        # C_out <= 4 3x3 convs (the image-space output / pyramid convs) have a dedicated exact kernel on the direct path
+        tail = self.ks == 3 and self.cout <= 4 and self.cin % 16 == 0 and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+        self.mfma = use_mfma(self.cin, self.cout) and self.ks in (1, 3) and not tail
         self.w = ops.pack_conv_weight(w) if self.mfma else ops.direct_weight(w)
         self.bias = conv.bias.detach().contiguous() if conv.bias is not None else None
 

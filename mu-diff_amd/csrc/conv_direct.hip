@@ -184,6 +184,77 @@ __global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_gr
   }
 }
 
+// Cout <= 4, 3x3, stride 1, pad 1, Cin % 16 == 0 (the generators' output convolution 64 -> 1 with its GroupNorm+SiLU
+// prologue and tanh epilogue, and the progressive='output_skip' pyramid convolutions): HBM-bound (reads Cin*4 B per
+// pixel, writes 4 B).  A 256-thread block owns an 8x32 output tile; the (8+2)x(32+2) halo tile is staged 16 input
+// channels at a time through LDS - loaded once as 16-B vectors, activated ONCE per element (the generic kernel applies
+// the prologue 9 times per element, the matrix-core kernel wastes 63 of its 64 output columns) - as 80-byte pixel
+// records (conflict-free ds_read_b128 at one pixel per lane); each thread then accumulates its pixel's 9 x 16 taps per
+// chunk from LDS with wave-uniform (scalar) weight loads.  Exact fp32 FMA chain.
+#define TAIL_ROWS 8
+#define TAIL_REC 20                               // floats per pixel record: 16 channels + 4 padding
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv_tail3x3(mud_conv_args a, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float tile[(TAIL_ROWS + 2) * 34 * TAIL_REC];
+  const int b = blockIdx.y;
+  const int ty0 = (blockIdx.x / tiles_x) * TAIL_ROWS, tx0 = (blockIdx.x % tiles_x) * 32;
+  const int tid = threadIdx.x, py = tid >> 5, px = tid & 31;      // this thread's output pixel inside the tile
+  const float* xb = a.x + (int64_t)b * a.H * a.W * a.ldx;
+  const float* wb = (const float*)((const char*)a.w + (int64_t)b * a.w_bstride);
+  float acc[COUT];
+#pragma unroll
+  for (int j = 0; j < COUT; ++j) acc[j] = 0.f;
+  constexpr int NPIX = (TAIL_ROWS + 2) * 34, ITEMS = NPIX * 4;
+  for (int c0 = 0; c0 < a.Cin; c0 += 16) {
+    // ---- stage 16 channels of the halo tile (prologue applied once per element; padding pixels are zeros)
+    for (int it = tid; it < ITEMS; it += 256) {
+      const int p = it >> 2, q = it & 3;
+      const int gy = ty0 + p / 34 - 1, gx = tx0 + p % 34 - 1;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v = *(const f32x4*)(xb + ((int64_t)gy * a.W + gx) * a.ldx + c0 + q * 4);
+        if (a.pro_mode == MUD_PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        } else if (a.pro_mode != MUD_PRO_NONE) {
+          const f32x4 sc = *(const f32x4*)(a.pro_scale + (int64_t)b * a.pro_ld + c0 + q * 4);
+          const f32x4 sh = *(const f32x4*)(a.pro_shift + (int64_t)b * a.pro_ld + c0 + q * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mud_prologue(v[e], sc[e], sh[e], a.pro_mode);
+        }
+      }
+      *(f32x4*)(tile + p * TAIL_REC + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float* rec = tile + ((py + t / 3) * 34 + px + t % 3) * TAIL_REC;
+      const float* wt = wb + ((int64_t)t * a.Cin + c0) * a.Cout;      // wave-uniform: [tap][ci][co]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(rec + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < COUT; ++j) acc[j] = fmaf(v[e], wt[(q * 4 + e) * COUT + j], acc[j]);
+      }
+    }
+    __syncthreads();
+  }
+  const int gy = ty0 + py, gx = tx0 + px;
+  if (gy < a.H && gx < a.W) {
+    const int64_t opix = ((int64_t)b * a.H + gy) * a.W + gx;
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) {
+      float v = acc[j];
+      if (a.bias) v += a.bias[j];
+      if (a.res) v += a.res[opix * a.ldr + j];
+      a.out[opix * a.ldo + j] = mud_act(v * a.out_scale, a.act);
+    }
+  }
+}
+
 extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(ap, "mud_conv2d_direct: null args");
   const mud_conv_args a = *ap;
@@ -209,6 +280,21 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
     hipLaunchKernelGGL(k_conv_head3x3, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups,
                        strips_per_row);
     MUD_CHECK_LAUNCH("mud_conv2d_direct(head)");
+    return MUD_OK;
+  }
+  if (a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cout <= 4 && a.Cin % 16 == 0 && vi4 && !a.emul && !a.egate && !a.stats && !a.bias2 && !a.sub2 &&
+      (a.pro_mode == MUD_PRO_NONE || a.pro_mode == MUD_PRO_LRELU || (a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift)))) {
+    MUD_REQUIRE(a.B <= 65535, "mud_conv2d_direct: B too large");
+    const int tiles_x = (int)mud_cdiv(a.W, 32), tiles_y = (int)mud_cdiv(a.H, TAIL_ROWS);
+    dim3 grid(tiles_x * tiles_y, a.B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (a.Cout) {
+      case 1: hipLaunchKernelGGL((k_conv_tail3x3<1>), grid, block, 0, s, a, tiles_x, tiles_y); break;
+      case 2: hipLaunchKernelGGL((k_conv_tail3x3<2>), grid, block, 0, s, a, tiles_x, tiles_y); break;
+      case 3: hipLaunchKernelGGL((k_conv_tail3x3<3>), grid, block, 0, s, a, tiles_x, tiles_y); break;
+      default: hipLaunchKernelGGL((k_conv_tail3x3<4>), grid, block, 0, s, a, tiles_x, tiles_y); break;
+    }
+    MUD_CHECK_LAUNCH("mud_conv2d_direct(tail)");
     return MUD_OK;
   }
   const int64_t total = (int64_t)Ho * Wo * co_groups;
