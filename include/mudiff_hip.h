@@ -111,6 +111,9 @@ typedef struct mud_conv_args {
                                                  /* squares) of the STORED outputs, stats[(b*stats_ld */
                                                  /* + co)*2 + {0,1}] += ... (fp64 atomics); lets the   */
                                                  /* next GroupNorm skip its pass over the tensor       */
+  int emul_cout;                                 /* `emul` applies to output channels < emul_cout only */
+                                                 /* (0 = all): lets two convs that share their input   */
+                                                 /* but differ in this epilogue run as one launch       */
 } mud_conv_args;
 
 /* Exact fp32 direct convolution (FMA chain per output), any ks/stride/pad/Cin/Cout.

@@ -226,14 +226,14 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
                  dense_w=torch.cat(dense_w, 0).contiguous(), dense_b=torch.cat(dense_b, 0).contiguous())
         p['convs'] = {e['idx']: layerspp.ConvParam(mods[e['idx']]) for e in self._plan if e['kind'] == 'conv'}
         if self.ADAPTIVE:
-            # the sigmoid gate convs share their input (reference :769-776): two convs of n_pairs*nf output channels -
-            # the att1 gates (multiplied by the feature they gate in the epilogue) and the att2 gates
-            for key, pre in (('g1', 'feat_att1_'), ('g2', 'feat_att2_')):
-                gates = [getattr(self, pre + pair) for pair in self._pairs]
-                wg = torch.cat([g.weight for g in gates], 0).contiguous()          # [n_pairs*nf, n_cond*nf, 3, 3]
-                p[key + '_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
-                p[key + '_w'] = ops.pack_conv_weight(wg) if p[key + '_mfma'] else ops.direct_weight(wg)
-                p[key + '_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
+            # all sigmoid gate convs share their input (reference :769-776): ONE conv of 2*n_pairs*nf output channels - first the
+            # att1 gates (multiplied by the feature they gate in the epilogue: emul on the first n_pairs*nf channels), then
+            # the att2 gates - so the concatenated condition features are staged once
+            gates = [getattr(self, 'feat_att1_' + pair) for pair in self._pairs] + [getattr(self, 'feat_att2_' + pair) for pair in self._pairs]
+            wg = torch.cat([g.weight for g in gates], 0).contiguous()              # [2*n_pairs*nf, n_cond*nf, 3, 3]
+            p['g_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
+            p['g_w'] = ops.pack_conv_weight(wg) if p['g_mfma'] else ops.direct_weight(wg)
+            p['g_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
             p['fw'] = [layerspp.ConvParam(getattr(self, f'feat_weight_c{j + 1}')) for j in range(len(self._pairs))]
             ada = [mods[e['idx']] for e in self._plan if e['kind'] == 'ada']
             p['ada_w'] = torch.cat([m.group_norm.style.weight for m in ada], 0).contiguous()
@@ -459,8 +459,9 @@ class _G2(_NCSNppBase):
             # att1 gates already multiplied by the feature they gate: sigmoid(conv(cat)) * c_i (pair k gates c_k: c12 -> c1,
             # c23 -> c2, c31 -> c3, reference :778,783,787); att2 gates: plain sigmoid
             npair = len(self._pairs)
-            gated = ops.conv(cat, p['g1_w'], 3, npair * nf, mfma=p['g1_mfma'], bias=p['g1_b'], act=ACT_SIGMOID, emul=cat.slice(0, npair * nf))
-            g2all = ops.conv(cat, p['g2_w'], 3, npair * nf, mfma=p['g2_mfma'], bias=p['g2_b'], act=ACT_SIGMOID)
+            gall = ops.conv(cat, p['g_w'], 3, 2 * npair * nf, mfma=p['g_mfma'], bias=p['g_b'], act=ACT_SIGMOID,
+                            emul=cat.slice(0, npair * nf), emul_cout=npair * nf)
+            gated, g2all = gall.slice(0, npair * nf), gall.slice(npair * nf, npair * nf)
             for j in range(npair):      # fused_ij = g2 * conv(g1 * c_i) + (1 - g2) * c_j   (reference :779-788)
                 other = (j + 1) % nc
                 p['fw'][j](gated.slice(j * nf, nf), gate=(g2all.slice(j * nf, nf), cat.slice(other * nf, nf)),

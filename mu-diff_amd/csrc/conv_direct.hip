@@ -17,20 +17,21 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
     for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) st_lds[i] = 0.f;
     __syncthreads();
   }
-  const int64_t total = (int64_t)Ho * Wo * co_groups;
+  // 32-bit index arithmetic (the launcher checks Ho*Wo*co_groups < 2^31): 64-bit div/mod are ~100-instruction routines
+  const unsigned total = (unsigned)Ho * (unsigned)Wo * (unsigned)co_groups;
   // loop stride = a multiple of co_groups, so a thread keeps its output-channel group and can fold the
   // statistics of all its outputs in registers (threads past the last whole multiple sit out)
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  const int64_t stride = (nthreads / co_groups) * co_groups;
-  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned nthreads = gridDim.x * blockDim.x;
+  const unsigned stride = (nthreads / (unsigned)co_groups) * (unsigned)co_groups;
+  const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % (unsigned)co_groups);            // constant along the loop
   float ssum[VO], ssq[VO];
 #pragma unroll
   for (int j = 0; j < VO; ++j) ssum[j] = ssq[j] = 0.f;
-  for (int64_t idx = first; first < stride && idx < total; idx += stride) {
-    const int cg = (int)(idx % co_groups);
-    int64_t p = idx / co_groups;
-    const int ox = (int)(p % Wo);
-    const int oy = (int)(p / Wo);
+  for (uint64_t idx64 = first; first < stride && idx64 < total; idx64 += stride) {
+    const unsigned p = (unsigned)idx64 / (unsigned)co_groups;
+    const int oy = (int)(p / (unsigned)Wo);
+    const int ox = (int)(p - (unsigned)oy * (unsigned)Wo);
     const int co = cg * VO;
     float acc[VO];
 #pragma unroll
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
       if (a.bias2) v += a.bias2[(int64_t)b * a.bias2_ld + co + j];
       if (a.res) v += a.res[opix * a.ldr + co + j];
       v = mud_act(v * a.out_scale, a.act);
-      if (a.emul) v *= a.emul[opix * a.ld_emul + co + j];
+      if (a.emul && (a.emul_cout <= 0 || co + j < a.emul_cout)) v *= a.emul[opix * a.ld_emul + co + j];
       if (a.egate) {
         const float gt = a.egate[opix * a.ld_egate + co + j];
         v = gt * v + (1.0f - gt) * a.eother[opix * a.ld_eother + co + j];
@@ -277,6 +278,13 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
     const int spb = 256 / co_groups, strips_per_row = (int)mud_cdiv(Wo, HEAD_PIX);
     int64_t blocks = mud_cdiv((int64_t)Ho * strips_per_row, spb);
     if (blocks > 256 * 16) blocks = 256 * 16;
+    if (a.stats) {
+      // every block ends with one fp64 atomic per channel on the SAME [b, channel] cells, and same-address atomics retire
+      // one at a time (~150 ns each in L2): 512 blocks per image cost 79 us of a 133 us launch.  Keep about 2048 blocks
+      // in total (8 per CU) and let each block walk more strips instead.
+      const int64_t per_image = 2048 / a.B > 16 ? 2048 / a.B : 16;
+      if (blocks > per_image) blocks = per_image;
+    }
     hipLaunchKernelGGL(k_conv_head3x3, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups,
                        strips_per_row);
     MUD_CHECK_LAUNCH("mud_conv2d_direct(head)");
@@ -301,7 +309,7 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   int64_t blocks = mud_cdiv(total, 256 * (a.stats ? 8 : 1));   // several outputs per thread when the block folds statistics
   if (blocks > 256 * 32) blocks = 256 * 32;
   while (blocks * 256 < co_groups) ++blocks;                   // the loop stride (a multiple of co_groups) must be positive
-  MUD_REQUIRE(a.B <= 65535, "mud_conv2d_direct: B too large");
+  MUD_REQUIRE(a.B <= 65535 && total < (1ll << 31) - (1ll << 24), "mud_conv2d_direct: B or image too large");
   MUD_REQUIRE(!a.stats || (a.stats_ld >= a.Cout && a.Cout <= 8192), "mud_conv2d_direct: bad stats view");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((int)blocks, a.B), block(256);

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   constexpr int EP_LD = 36;                                     // floats per staged pixel row (16-B aligned, bank-spread)
   float* ep = (float*)smem + wave * (32 * EP_LD);               // the A buffers are dead after the last barrier
   float* st_lds = (float*)smem + WM * WN * (32 * EP_LD);        // [wave][64 ch][2]
-  const bool vec = ((a.Cout | a.ldo | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
+  const int emul_lim = a.emul_cout > 0 ? a.emul_cout : a.Cout;       // emul covers channels [0, emul_lim)
+  const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
 #pragma unroll
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
             }
-            if (a.emul) v *= *(const f32x4*)(a.emul + opix * a.ld_emul + co4);
+            if (a.emul && co4 < emul_lim) v *= *(const f32x4*)(a.emul + opix * a.ld_emul + co4);
             if (a.egate) {
               const f32x4 gt = *(const f32x4*)(a.egate + opix * a.ld_egate + co4);
               v = gt * v + (1.0f - gt) * *(const f32x4*)(a.eother + opix * a.ld_eother + co4);
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
             float v = acc[m][n][reg] + badd;
             if (a.res) v += a.res[opix * a.ldr + co];
             v = mud_act(v * a.out_scale, a.act);
-            if (a.emul) v *= a.emul[opix * a.ld_emul + co];
+            if (a.emul && co < emul_lim) v *= a.emul[opix * a.ld_emul + co];
             if (a.egate) {
               const float gt = a.egate[opix * a.ld_egate + co];
               v = gt * v + (1.0f - gt) * a.eother[opix * a.ld_eother + co];
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
   constexpr int EP_LD = 36;                                     // floats per staged pixel row (16-B aligned, bank-spread)
   float* ep = (float*)smem + wave * (32 * EP_LD);               // the A buffers are dead after the last barrier
   float* st_lds = (float*)smem + 4 * (32 * EP_LD);              // [wave][64 ch][2]
-  const bool vec = ((a.Cout | a.ldo | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
+  const int emul_lim = a.emul_cout > 0 ? a.emul_cout : a.Cout;       // emul covers channels [0, emul_lim)
+  const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
 #pragma unroll
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
             }
-            if (a.emul) v *= *(const f32x4*)(a.emul + opix * a.ld_emul + co4);
+            if (a.emul && co4 < emul_lim) v *= *(const f32x4*)(a.emul + opix * a.ld_emul + co4);
             if (a.egate) {
               const f32x4 gt = *(const f32x4*)(a.egate + opix * a.ld_egate + co4);
               v = gt * v + (1.0f - gt) * *(const f32x4*)(a.eother + opix * a.ld_eother + co4);
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
             float v = acc[m][n][reg] + badd;
             if (a.res) v += a.res[opix * a.ldr + co];
             v = mud_act(v * a.out_scale, a.act);
-            if (a.emul) v *= a.emul[opix * a.ld_emul + co];
+            if (a.emul && co < emul_lim) v *= a.emul[opix * a.ld_emul + co];
             if (a.egate) {
               const float gt = a.egate[opix * a.ld_egate + co];
               v = gt * v + (1.0f - gt) * a.eother[opix * a.ld_eother + co];
@@ -812,7 +814,8 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(a.ldo >= a.Cout && (!a.res || a.ldr >= a.Cout), "mud_conv2d_mfma: bad output/residual view");
   MUD_REQUIRE(!a.stats || a.stats_ld >= a.Cout, "mud_conv2d_mfma: bad stats view");
   MUD_REQUIRE(!a.sub2 || (a.ks == 3 && (a.H & 1) && (a.W & 1)), "mud_conv2d_mfma: sub2 needs ks == 3 and odd H, W");
-  MUD_REQUIRE((!a.emul || a.ld_emul >= a.Cout) && (!a.egate || (a.eother && a.ld_egate >= a.Cout && a.ld_eother >= a.Cout)), "mud_conv2d_mfma: bad emul / egate / eother view");
+  MUD_REQUIRE(a.emul_cout >= 0 && a.emul_cout <= a.Cout, "mud_conv2d_mfma: emul_cout out of range");
+  MUD_REQUIRE((!a.emul || a.ld_emul >= (a.emul_cout > 0 ? a.emul_cout : a.Cout)) && (!a.egate || (a.eother && a.ld_egate >= a.Cout && a.ld_eother >= a.Cout)), "mud_conv2d_mfma: bad emul / egate / eother view");
   MUD_REQUIRE(a.pro_mode >= MUD_PRO_NONE && a.pro_mode <= MUD_PRO_LRELU, "mud_conv2d_mfma: unknown prologue mode %d", a.pro_mode);
   if (a.pro_mode == MUD_PRO_AFFINE || a.pro_mode == MUD_PRO_AFFINE_SILU) {
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),

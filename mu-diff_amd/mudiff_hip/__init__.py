@@ -39,6 +39,7 @@ class ConvArgs(C.Structure):
         ('out', C.c_void_p), ('Cout', C.c_int), ('ldo', C.c_int),
         ('sub2', C.c_int),
         ('stats', C.c_void_p), ('stats_ld', C.c_int),
+        ('emul_cout', C.c_int),
     ]
 
 

@@ -268,7 +268,7 @@ def direct_weight(w_oihw):
 
 
 def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None, bias2=None, res: View = None,
-         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None, sub2=False, emul: View = None, gate=None):
+         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None, sub2=False, emul: View = None, gate=None, emul_cout=0):
     """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode)."""
     lib = load()
     pad = ks // 2 if pad is None else pad
@@ -303,9 +303,9 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
         a.res, a.ldr = res.ptr, res.ld
     a.out_scale, a.act = out_scale, act
     a.sub2 = 1 if sub2 else 0
-    if emul is not None:          # v *= emul
-        assert (emul.B, emul.H, emul.W, emul.C) == (x.B, Ho, Wo, Cout)
-        a.emul, a.ld_emul = emul.ptr, emul.ld
+    if emul is not None:          # v *= emul (on the first emul_cout output channels only, when given)
+        assert (emul.B, emul.H, emul.W, emul.C) == (x.B, Ho, Wo, emul_cout or Cout)
+        a.emul, a.ld_emul, a.emul_cout = emul.ptr, emul.ld, emul_cout
     if gate is not None:          # v = g*v + (1-g)*other
         gv, ov = gate
         assert (gv.B, gv.H, gv.W, gv.C) == (x.B, Ho, Wo, Cout) == (ov.B, ov.H, ov.W, ov.C)
