@@ -207,10 +207,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   store_a(0, smem);
   __syncthreads();
 
+  // ---- residual prefetch: the epilogue adds a [pixels x channels] tile of `res` the size of the accumulators.  Loaded
+  // there, its HBM time is paid after the MFMAs (a 128->128 layer at 256x256 ran 12 % longer with a residual); loaded
+  // into registers a few chunks before the end, it streams in underneath them.  Same lane <-> (pixel, 4 channels) mapping
+  // as the epilogue's vector path.
+  const int emul_lim = a.emul_cout > 0 ? a.emul_cout : a.Cout;       // emul covers channels [0, emul_lim)
+  const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
+                   mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
+                   (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
+  const bool pre_res = KS == 3 && WM * WN >= 8 && a.res && vec && !a.sub2;      // (the 4-wave variants have no registers to spare)
+  f32x4 rpre[2][MT][4];
+  const int kc_pre = nchunks > 3 ? nchunks - 3 : 0;
+  auto prefetch_res = [&]() {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int co4 = (nt * WN + wn) * CM_BN + n * 32 + (lane & 7) * 4;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int gy = ty0 + wm * MT + m, gx = tx0 + pass * 8 + (lane >> 3);
+          const bool ok = gy < a.H && gx < a.W && co4 < a.Cout;
+          const int64_t opix = ((int64_t)b * a.H + (ok ? gy : 0)) * a.W + (ok ? gx : 0);
+          const f32x4 v = *(const f32x4*)(a.res + opix * a.ldr + (ok ? co4 : 0));
+          rpre[n][m][pass] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  };
+
   for (int kc = 0; kc < nchunks; ++kc) {
     char* cur = smem + (kc & 1) * G::BUF;
     char* nxt = smem + ((kc + 1) & 1) * G::BUF;
     const bool more = kc + 1 < nchunks;
+    if (pre_res && kc == kc_pre) prefetch_res();
 #pragma unroll
     for (int g = 0; g < G::NG; ++g) {
       const int gg = kc * G::NG + g;
@@ -264,10 +293,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   constexpr int EP_LD = 36;                                     // floats per staged pixel row (16-B aligned, bank-spread)
   float* ep = (float*)smem + wave * (32 * EP_LD);               // the A buffers are dead after the last barrier
   float* st_lds = (float*)smem + WM * WN * (32 * EP_LD);        // [wave][64 ch][2]
-  const int emul_lim = a.emul_cout > 0 ? a.emul_cout : a.Cout;       // emul covers channels [0, emul_lim)
-  const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
-                   mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
-                   (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int co = (nt * WN + wn) * CM_BN + n * 32 + r;
@@ -301,7 +326,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
           }
           f32x4 v = *(const f32x4*)(ep + prow * EP_LD + col);
           if (valid && co4 < a.Cout) {
-            if (a.res) v += *(const f32x4*)(a.res + opix * a.ldr + co4);
+            if (pre_res) v += rpre[n][m][pass];
+            else if (a.res) v += *(const f32x4*)(a.res + opix * a.ldr + co4);
             v *= a.out_scale;
             if (a.act != MUD_ACT_NONE) {
 #pragma unroll
