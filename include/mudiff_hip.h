@@ -154,9 +154,13 @@ int mud_minibatch_stddev(const float* x, int B, int64_t hw, int C, int ld, int g
 
 /* ---- fused attention (layerspp.py:118-122): out[b,i,:] = sum_j softmax_j(q_i.k_j * scale) v_j, single head.
  * qkv: [B, N, ld] with q at +0, k at +C, v at +2C (the fused NIN_0|1|2 output); out [B, N, ldo].
- * Flash-style (no N x N matrix in memory), split-bf16 MFMA.  Head dims: see mud_attention_supported(). */
+ * Flash-style (no N x N matrix in memory), split-bf16 MFMA.  Head dims: see mud_attention_supported().
+ * When batch x ceil(N/128) workgroups would leave most CUs idle (single-slice latency case) the keys are split over
+ * up to 16 workgroups per query block and merged by a second tiny kernel; that needs `ws` (mud_attention_ws_bytes(),
+ * 16-byte aligned).  ws == NULL always runs unsplit. */
 int mud_attention_supported(int C);
-int mud_attention(const float* qkv, int B, int N, int C, int ld, float scale, float* out, int ldo, void* stream);
+int64_t mud_attention_ws_bytes(int B, int N, int C);   /* 0 = no workspace needed for this problem */
+int mud_attention(const float* qkv, int B, int N, int C, int ld, float scale, float* out, int ldo, void* ws, void* stream);
 
 /* ---- unfused attention pieces (used when the head dim is not supported above) and the G2 feature fusion (…feat.py:769-788) */
 int mud_softmax_rows(float* s, int64_t rows, int n, int ld, void* stream);          /* in place */

@@ -32,7 +32,7 @@ struct AtGeo {
 
 template <int C16>
 __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ qkv, int N, int ld, float scale_log2,
-                                                       float* __restrict__ out, int ldo) {
+                                                       float* __restrict__ out, int ldo, int tiles_per_split, float* __restrict__ part) {
   using G = AtGeo<C16>;
   constexpr int C = G::C, CT = G::CT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
   const int b = blockIdx.y;
   const int qi = blockIdx.x * 128 + wave * 32 + r;              // this lane's query (both half-waves hold the same 32 queries)
   const float* base = qkv + (int64_t)b * N * ld;
-  const int ntiles = (N + 31) / 32;
+  // key range of this workgroup: all of it, or - when there are too few (batch x query-block) workgroups to fill the chip -
+  // one of gridDim.z slices; the partial (unnormalised O, running max, running sum) results are merged by k_attention_combine
+  const int kt0 = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, kt0 + tiles_per_split);
 
   // ---- Q^T B-fragments, split once: lane (query r, k half hh) holds channels 16s + 8hh .. +7 of its query
   bf16x8 qh[C16], ql[C16];
@@ -132,15 +135,15 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
     for (int i = 0; i < 16; ++i) o[ct][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  fetch_k(0);
+  fetch_k(kt0);
   stash_k(smem);
-  fetch_v(0);
+  fetch_v(kt0);
   stash_v(smem);
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const char* cur = smem + (kt & 1) * G::BUF;
-    char* nxt = smem + ((kt + 1) & 1) * G::BUF;
+  for (int kt = kt0; kt < ntiles; ++kt) {
+    const char* cur = smem + ((kt - kt0) & 1) * G::BUF;
+    char* nxt = smem + ((kt - kt0 + 1) & 1) * G::BUF;
     const bool more = kt + 1 < ntiles;
     if (more) fetch_k(kt + 1);          // next K tile: in flight during S^T, parked in LDS right after it
 
@@ -222,6 +225,20 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
 
   // ---- normalise and store: lane = query, register i of tile ct is channel ct*32 + (i&3) + 8(i>>2) + 4hh
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (part) {             // split keys: part[b][split][query][C + 2] = unnormalised O^T column, running max (log2 domain), running sum
+    if (qi < N) {
+      float* pp = part + (((int64_t)b * gridDim.z + blockIdx.z) * N + qi) * (C + 4);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int c0 = ct * 32 + 8 * q4 + 4 * hh;
+          if (c0 < C) *(f32x4*)(pp + c0) = f32x4{o[ct][4 * q4], o[ct][4 * q4 + 1], o[ct][4 * q4 + 2], o[ct][4 * q4 + 3]};
+        }
+      if (hh == 0) { pp[C] = m_run; pp[C + 1] = l_tot; }
+    }
+    return;
+  }
   const float inv = 1.0f / l_tot;
   if (qi < N) {
     float* op = out + ((int64_t)b * N + qi) * ldo;
@@ -238,8 +255,42 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
   }
 }
 
+// out[b, q, :] = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s,  m = max_s m_s   (one thread per 4 channels)
+__global__ __launch_bounds__(256) void k_attention_combine(const float* __restrict__ part, int N, int C, int nsplit, float* __restrict__ out, int ldo) {
+  const int C4 = C / 4;
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= (unsigned)(N * C4)) return;
+  const int q = (int)(t / (unsigned)C4), c = (int)(t - (unsigned)q * (unsigned)C4) * 4, b = blockIdx.y;
+  const int64_t row = C + 4;
+  const float* p0 = part + ((int64_t)b * nsplit * N + q) * row;
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, p0[(int64_t)s * N * row + C]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* ps = p0 + (int64_t)s * N * row;
+    const float w = __builtin_amdgcn_exp2f(ps[C] - m);
+    acc += w * *(const f32x4*)(ps + c);
+    l += w * ps[C + 1];
+  }
+  *(f32x4*)(out + ((int64_t)b * N + q) * ldo + c) = acc * (1.0f / l);
+}
+
+// Key splits used for (B, N): 1 unless the (batch x 128-query block) grid leaves most of the 256 CUs idle.
+static int at_splits(int B, int N) {
+  const int64_t wgs = (int64_t)B * mud_cdiv(N, 128);
+  const int ntiles = (int)mud_cdiv(N, 32);
+  if (wgs >= 128 || ntiles < 8) return 1;
+  int ns = (int)mud_cdiv(256, wgs);
+  if (ns > 16) ns = 16;
+  if (ns > ntiles / 4) ns = ntiles / 4;               // at least 4 key tiles (128 keys) per split
+  if (ns < 1) ns = 1;
+  const int tps = (int)mud_cdiv(ntiles, ns);
+  return (int)mud_cdiv(ntiles, tps);                  // no empty split
+}
+
 template <int C16>
-static int at_launch(const float* qkv, int B, int N, int ld, float scale, float* out, int ldo, hipStream_t s) {
+static int at_launch(const float* qkv, int B, int N, int ld, float scale, float* out, int ldo, float* ws, hipStream_t s) {
   using G = AtGeo<C16>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -250,26 +301,39 @@ static int at_launch(const float* qkv, int B, int N, int ld, float scale, float*
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_attention<C16>), dim3((unsigned)mud_cdiv(N, 128), B), dim3(256), G::LDS_BYTES, s, qkv, N, ld,
-                     scale * 1.44269504088896340736f, out, ldo);
+  const int ntiles = (int)mud_cdiv(N, 32);
+  const int ns = ws ? at_splits(B, N) : 1;
+  const int tps = (int)mud_cdiv(ntiles, ns);
+  hipLaunchKernelGGL((k_attention<C16>), dim3((unsigned)mud_cdiv(N, 128), B, ns), dim3(256), G::LDS_BYTES, s, qkv, N, ld,
+                     scale * 1.44269504088896340736f, out, ldo, tps, ns > 1 ? ws : (float*)nullptr);
   MUD_CHECK_LAUNCH("mud_attention");
+  if (ns > 1) {
+    hipLaunchKernelGGL(k_attention_combine, dim3((unsigned)mud_cdiv((int64_t)N * (G::C / 4), 256), B), dim3(256), 0, s, ws, N, G::C, ns, out, ldo);
+    MUD_CHECK_LAUNCH("mud_attention(combine)");
+  }
   return MUD_OK;
+}
+
+extern "C" int64_t mud_attention_ws_bytes(int B, int N, int C) {
+  if (B <= 0 || N <= 0 || C <= 0) return 0;
+  const int ns = at_splits(B, N);
+  return ns > 1 ? (int64_t)B * ns * N * (C + 4) * 4 : 0;
 }
 
 extern "C" int mud_attention_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128 || C == 256; }
 
-extern "C" int mud_attention(const float* qkv, int B, int N, int C, int ld, float scale, float* out, int ldo, void* stream) {
+extern "C" int mud_attention(const float* qkv, int B, int N, int C, int ld, float scale, float* out, int ldo, void* ws, void* stream) {
   MUD_REQUIRE(qkv && out, "mud_attention: null pointer");
   MUD_REQUIRE(B >= 0 && B <= 65535 && N > 0 && ld >= 3 * C && ldo >= C, "mud_attention: bad sizes");
   MUD_REQUIRE(mud_attention_supported(C), "mud_attention: head dim %d not in {16,32,64,128,256}", C);
-  MUD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && mud_aligned16(qkv) && mud_aligned16(out), "mud_attention: needs ld %% 4 == 0 and 16-byte aligned buffers");
+  MUD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && mud_aligned16(qkv) && mud_aligned16(out) && mud_aligned16(ws), "mud_attention: needs ld %% 4 == 0 and 16-byte aligned buffers");
   if (B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
-    case 16: return at_launch<1>(qkv, B, N, ld, scale, out, ldo, s);
-    case 32: return at_launch<2>(qkv, B, N, ld, scale, out, ldo, s);
-    case 64: return at_launch<4>(qkv, B, N, ld, scale, out, ldo, s);
-    case 128: return at_launch<8>(qkv, B, N, ld, scale, out, ldo, s);
-    default: return at_launch<16>(qkv, B, N, ld, scale, out, ldo, s);
+    case 16: return at_launch<1>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
+    case 32: return at_launch<2>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
+    case 64: return at_launch<4>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
+    case 128: return at_launch<8>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
+    default: return at_launch<16>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
   }
 }

@@ -64,7 +64,8 @@ _SIGNATURES = {
     'mud_fir_nhwc': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
     'mud_minibatch_stddev': (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     'mud_attention_supported': (_I, [_I]),
-    'mud_attention': (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P]),
+    'mud_attention_ws_bytes': (_L, [_I, _I, _I]),
+    'mud_attention': (_I, [_P, _I, _I, _I, _I, _F, _P, _I, _P, _P]),
     'mud_softmax_rows': (_I, [_P, _L, _I, _I, _P]),
     'mud_mul': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
     'mud_gate_mix': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _L, _I, _P, _I, _P]),

@@ -373,8 +373,10 @@ def attention(qkv: View, C_, scale):
     assert qkv.C == 3 * C_
     n = qkv.H * qkv.W
     out = View.empty(qkv.B, qkv.H, qkv.W, C_, qkv.device)
-    _launch('attention', load().mud_attention, qkv.ptr, qkv.B, n, C_, qkv.ld, float(scale), out.ptr, out.ld, stream_ptr(),
-            flops=4.0 * qkv.B * n * n * C_)
+    nws = load().mud_attention_ws_bytes(qkv.B, n, C_)        # > 0: few workgroups, the keys are split and merged
+    ws = torch.empty(nws // 4, device=qkv.device, dtype=torch.float32) if nws else None
+    _launch('attention', load().mud_attention, qkv.ptr, qkv.B, n, C_, qkv.ld, float(scale), out.ptr, out.ld, ptr(ws) if nws else None,
+            stream_ptr(), flops=4.0 * qkv.B * n * n * C_)
     return out
 
 

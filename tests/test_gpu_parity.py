@@ -241,6 +241,29 @@ def test_attention_block_fused_and_unfused(B, H, W, C):
     assert err < 5e-5
 
 
+@pytest.mark.parametrize('B,N,C', [(1, 4096, 256), (1, 1440, 64), (3, 1000, 32), (1, 260, 128)])
+def test_attention_key_split_matches_unsplit(B, N, C):
+    """Few (batch x query-block) workgroups: the keys are split over several workgroups and merged (mud_attention with a
+    workspace).  Same result as the unsplit kernel (ws = NULL) up to the merge's rounding, and as fp64 softmax attention."""
+    import mudiff_hip
+    ops, *_ = _imports()
+    lib = mudiff_hip.load()
+    gen = torch.Generator().manual_seed(N + C)
+    qkv = g(torch.randn(B, N, 3 * C, generator=gen))
+    nws = lib.mud_attention_ws_bytes(B, N, C)
+    assert nws > 0
+    v = ops.View(qkv, B, 1, N, 3 * C)
+    split = ops.attention(v, C, C ** -0.5).tensor().reshape(B, N, C)
+    unsplit = torch.empty(B, N, C, device=DEV)
+    rc = lib.mud_attention(qkv.data_ptr(), B, N, C, 3 * C, C ** -0.5, unsplit.data_ptr(), C, None, None)
+    assert rc == 0
+    q, k, vv = (t.double().cpu() for t in qkv.split(C, dim=2))
+    ref = torch.softmax(q @ k.transpose(1, 2) * C ** -0.5, dim=-1) @ vv
+    print(f'attention split B={B} N={N} C={C}: split-unsplit {maxdiff(split, unsplit):.2e}, split-fp64 {maxdiff(split, ref):.2e}')
+    assert maxdiff(split, unsplit) <= 2e-6 and maxdiff(split, ref) <= 2e-5
+    assert lib.mud_attention_ws_bytes(16, 4096, 256) == 0          # enough workgroups: no split, no workspace
+
+
 def test_blocks_against_reference_golden():
     ops, S, L, UD, *_ = _imports()
     import torch.nn as nn
@@ -443,7 +466,7 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert lib.mud_upfirdn2d(x.data_ptr(), 1, 8, 8, k.data_ptr(), 9, 9, 1, 1, 1, 1, 4, 4, 4, 4, out.data_ptr(), None) == 1
     # attention: unsupported head dim is reported, not launched
     assert lib.mud_attention_supported(24) == 0 and lib.mud_attention_supported(256) == 1
-    assert lib.mud_attention(x.data_ptr(), 1, 64, 24, 72, ctypes.c_float(1.0), out.data_ptr(), 24, None) != 0
+    assert lib.mud_attention(x.data_ptr(), 1, 64, 24, 72, ctypes.c_float(1.0), out.data_ptr(), 24, None, None) != 0
     # conv: channel pitch smaller than the channel count, misaligned base pointer
     xv = ops.View(x, 1, 8, 8, 16)
     w = ops.pack_conv_weight(torch.zeros(64, 16, 3, 3, device=DEV))
