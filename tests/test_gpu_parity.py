@@ -86,7 +86,7 @@ def test_embeddings_and_dense():
     z = torch.randn(5, 100, generator=gen)
     ref = z / torch.sqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
     assert maxdiff(ops.pixel_norm(g(z)), ref) < 1e-6
-    for B, K, N in ((5, 100, 256), (1, 256, 1024), (9, 64, 33), (32, 256, 512)):
+    for B, K, N in ((5, 100, 256), (1, 256, 1024), (9, 64, 33), (32, 256, 512), (20, 256, 11520), (3, 102, 70), (2, 1024, 65)):
         x, W, b = torch.randn(B, K, generator=gen), torch.randn(N, K, generator=gen) / math.sqrt(K), torch.randn(N, generator=gen)
         assert maxdiff(ops.dense(g(x), g(W), g(b)), F.linear(x, W, b)) < 5e-6
         assert maxdiff(ops.dense(g(x), g(W), g(b), act_in=ops.ACT_SILU, act_out=ops.ACT_SILU), F.silu(F.linear(F.silu(x), W, b))) < 5e-6
