@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, in
 // (clamped address x 0/1 mask), and reused by the 9 taps.  co_groups lanes cover one pixel's channels, so
 // stores are 16 B per lane in runs of 4*co_groups*4 B (256 B for 64 channels).
 #define HEAD_PIX 8
-__global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_groups, int strips_per_row) {
+template <int S>                               // stride: 1 (pad 1: head convs) or 2 (pad 0: the input-pyramid conv after its FIR)
+__global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_groups, int strips_per_row, int Ho, int Wo) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* st_lds = (float*)smem_raw;
   const int b = blockIdx.y;
@@ -133,19 +134,20 @@ __global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_gr
   const int64_t HW = (int64_t)a.H * a.W;
   const float* xb = a.x + (int64_t)b * HW * a.ldx;
   f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
-  const int64_t nstrips = (int64_t)a.H * strips_per_row;
+  const int64_t nstrips = (int64_t)Ho * strips_per_row;
+  constexpr int WIN = S * (HEAD_PIX - 1) + 3;       // input columns under a strip
   const bool active = ls < spb;
   for (int64_t st = (int64_t)blockIdx.x * spb + ls; active && st < nstrips; st += (int64_t)gridDim.x * spb) {
     const int y = (int)(st / strips_per_row), x0 = (int)(st - (int64_t)y * strips_per_row) * HEAD_PIX;
-    float win[3][HEAD_PIX + 2];
+    float win[3][WIN];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      const int iy = y + dy - 1;
+      const int iy = y * S + dy - a.pad;
       const bool yok = iy >= 0 && iy < a.H;
       const int64_t rowoff = (int64_t)(yok ? iy : 0) * a.W;
 #pragma unroll
-      for (int j = 0; j < HEAD_PIX + 2; ++j) {
-        const int ix = x0 + j - 1;
+      for (int j = 0; j < WIN; ++j) {
+        const int ix = x0 * S + j - a.pad;
         const bool ok = yok && ix >= 0 && ix < a.W;
         const float v = xb[(rowoff + (ok ? ix : 0)) * a.ldx];
         win[dy][j] = ok ? v : 0.f;
@@ -153,13 +155,13 @@ __global__ __launch_bounds__(256) void k_conv_head3x3(mud_conv_args a, int co_gr
     }
 #pragma unroll
     for (int k = 0; k < HEAD_PIX; ++k) {
-      if (x0 + k >= a.W) break;
+      if (x0 + k >= Wo) break;
       f32x4 acc = bias;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) acc += win[dy][k + dx] * w[dy * 3 + dx];
-      const int64_t opix = (int64_t)b * HW + (int64_t)y * a.W + x0 + k;
+        for (int dx = 0; dx < 3; ++dx) acc += win[dy][k * S + dx] * w[dy * 3 + dx];
+      const int64_t opix = ((int64_t)b * Ho + y) * Wo + x0 + k;
       if (a.res) acc += *(const f32x4*)(a.res + opix * a.ldr + co);
       acc *= a.out_scale;
       if (a.act != MUD_ACT_NONE) {
@@ -271,7 +273,7 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
   const bool vo4 = a.Cout % 4 == 0 && a.ldo % 4 == 0 && mud_aligned16(a.out) && mud_aligned16(a.w) && (a.w_bstride % 16 == 0);
   const bool vi4 = a.Cin % 4 == 0 && a.ldx % 4 == 0 && mud_aligned16(a.x);
   const int co_groups = vo4 ? a.Cout / 4 : a.Cout;
-  if (a.Cin == 1 && a.ks == 3 && a.stride == 1 && a.pad == 1 && vo4 && !a.emul && !a.egate && co_groups <= 256 && a.pro_mode == MUD_PRO_NONE && a.w_bstride == 0 &&
+  if (a.Cin == 1 && a.ks == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) && vo4 && !a.emul && !a.egate && co_groups <= 256 && a.pro_mode == MUD_PRO_NONE && a.w_bstride == 0 &&
       (!a.res || (a.ldr % 4 == 0 && mud_aligned16(a.res))) && (!a.bias || mud_aligned16(a.bias)) &&
       (!a.bias2 || (a.bias2_ld % 4 == 0 && mud_aligned16(a.bias2)))) {
     MUD_REQUIRE(a.B <= 65535 && (!a.stats || a.stats_ld >= a.Cout), "mud_conv2d_direct: bad batch / stats view");
@@ -285,8 +287,12 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
       const int64_t per_image = 2048 / a.B > 16 ? 2048 / a.B : 16;
       if (blocks > per_image) blocks = per_image;
     }
-    hipLaunchKernelGGL(k_conv_head3x3, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups,
-                       strips_per_row);
+    if (a.stride == 1)
+      hipLaunchKernelGGL(k_conv_head3x3<1>, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups,
+                         strips_per_row, Ho, Wo);
+    else
+      hipLaunchKernelGGL(k_conv_head3x3<2>, dim3((int)blocks, a.B), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, (hipStream_t)stream, a, co_groups,
+                         strips_per_row, Ho, Wo);
     MUD_CHECK_LAUNCH("mud_conv2d_direct(head)");
     return MUD_OK;
   }
