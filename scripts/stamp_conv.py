@@ -1,0 +1,32 @@
+"""Phase breakdown of the 3x3 conv kernel from in-kernel cycle stamps (needs the instrumented build scripts/exp/libstamp.so)."""
+import ctypes, sys, math
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/mu-diff_amd')
+import numpy as np, torch
+import mudiff_hip
+from mudiff_hip import ops
+lib = mudiff_hip.load()
+lib.mud_debug_read_stamps.restype = ctypes.c_int
+lib.mud_debug_read_stamps.argtypes = [ctypes.c_void_p]
+B, dev = 16, 'cuda:0'
+for H, Cin, Cout, res in [(256, 64, 64, True), (256, 64, 64, False), (128, 128, 128, True), (64, 256, 256, False), (256, 320, 64, False)]:
+    x = ops.View(torch.randn(B, H, H, Cin, device=dev), B, H, H, Cin)
+    w = ops.pack_conv_weight(torch.randn(Cout, Cin, 3, 3, device=dev) / math.sqrt(Cin * 9))
+    sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev)
+    r = ops.View(torch.randn(B, H, H, Cout, device=dev), B, H, H, Cout) if res else None
+    arena = ops.StatsArena(dev)
+    out = ops.View.empty(B, H, H, Cout, dev, arena)
+    for _ in range(3):
+        ops.conv(x, w, 3, Cout, mfma=True, pro=(sc, sh, ops.PRO_AFFINE_SILU), res=r, out=out)
+    torch.cuda.synchronize()
+    buf = np.zeros(64 * 64, dtype=np.uint64)
+    assert lib.mud_debug_read_stamps(buf.ctypes.data) == 0
+    st = buf.reshape(64, 64).astype(np.int64)
+    nch = (Cin + 15) // 16
+    tot = st[:, 62] - st[:, 0]
+    pro = st[:, 1] - st[:, 0]
+    loop = st[:, 60] - st[:, 1]
+    epi = st[:, 61] - st[:, 60]
+    tail = st[:, 62] - st[:, 61]
+    chunk = (st[:, 2 + nch - 1] - st[:, 2]) / max(nch - 1, 1)
+    f = lambda a: f'{np.median(a):8.0f}'
+    print(f'{H}^2 {Cin}->{Cout} res={int(res)}: cycles(median over 64 blocks, 100 MHz counter?) total{f(tot)} prologue{f(pro)} loop{f(loop)} (per chunk{f(chunk)}, {nch} chunks) epilogue{f(epi)} stats+end{f(tail)}')
