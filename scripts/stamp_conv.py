@@ -7,7 +7,7 @@ from mudiff_hip import ops
 lib = mudiff_hip.load()
 lib.mud_debug_read_stamps.restype = ctypes.c_int
 lib.mud_debug_read_stamps.argtypes = [ctypes.c_void_p]
-B, dev = 16, 'cuda:0'
+B, dev = (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 'cuda:0'
 for H, Cin, Cout, res in [(256, 64, 64, True), (256, 64, 64, False), (128, 128, 128, True), (64, 256, 256, False), (256, 320, 64, False)]:
     x = ops.View(torch.randn(B, H, H, Cin, device=dev), B, H, H, Cin)
     w = ops.pack_conv_weight(torch.randn(Cout, Cin, 3, 3, device=dev) / math.sqrt(Cin * 9))
@@ -29,4 +29,6 @@ for H, Cin, Cout, res in [(256, 64, 64, True), (256, 64, 64, False), (128, 128, 
     tail = st[:, 62] - st[:, 61]
     chunk = (st[:, 2 + nch - 1] - st[:, 2]) / max(nch - 1, 1)
     f = lambda a: f'{np.median(a):8.0f}'
+    grp = [int(np.median(st[:, 40 + i] - (st[:, 2 + 2] if i == 0 else st[:, 39 + i]))) for i in range(6)]
+    print('   chunk 2: [group MFMAs+staging, barrier wait] x3 =', grp)
     print(f'{H}^2 {Cin}->{Cout} res={int(res)}: cycles(median over 64 blocks, 100 MHz counter?) total{f(tot)} prologue{f(pro)} loop{f(loop)} (per chunk{f(chunk)}, {nch} chunks) epilogue{f(epi)} stats+end{f(tail)}')
