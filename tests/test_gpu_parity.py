@@ -126,6 +126,39 @@ def test_conv_direct(B, H, W, Cin, Cout, ks, stride, pad):
     assert maxdiff(out.to_nchw(), F.conv2d(x, w, b, stride=stride, padding=pad)) < 1e-5
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 19, 45, 64, 1), (1, 8, 32, 16, 2), (3, 33, 70, 48, 3), (1, 9, 7, 32, 4)])
+def test_tail_conv_kernel(B, H, W, Cin, Cout):
+    """The LDS-tiled C_out <= 4 kernel (output / pyramid convolutions): ragged tiles, GroupNorm+SiLU prologue, residual, tanh,
+    against torch fp32; and the strip kernel on the stride-2 pyramid convolution (C_in = 1) with residual + statistics."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, H, W, generator=gen)
+    sc, sh = torch.rand(B, Cin, generator=gen) + 0.5, torch.randn(B, Cin, generator=gen)
+    xv = ops.View.from_nchw(g(x))
+    out = ops.conv(xv, ops.direct_weight(g(w)), 3, Cout, mfma=False, bias=g(b))
+    assert maxdiff(out.to_nchw(), F.conv2d(x, w, b, padding=1)) < 1e-5
+    out = ops.conv(xv, ops.direct_weight(g(w)), 3, Cout, mfma=False, bias=g(b), pro=(g(sc), g(sh), ops.PRO_AFFINE_SILU),
+                   res=ops.View.from_nchw(g(res)), out_scale=0.7, act=ops.ACT_TANH)
+    ref = torch.tanh((F.conv2d(F.silu(x * sc[:, :, None, None] + sh[:, :, None, None]), w, b, padding=1) + res) * 0.7)
+    assert maxdiff(out.to_nchw(), ref) < 2e-5
+    # stride-2 pad-0 conv of a single-channel image (the input pyramid after its FIR): strip kernel, residual, statistics
+    Hs, Ws = 2 * H + 1, 2 * W + 1
+    xs = torch.randn(B, 1, Hs, Ws, generator=gen)
+    ws = torch.randn(64, 1, 3, 3, generator=gen) / 3
+    bs = torch.randn(64, generator=gen)
+    rs = torch.randn(B, 64, H, W, generator=gen)
+    arena = ops.StatsArena(DEV)
+    o = ops.View.empty(B, H, W, 64, DEV, arena)
+    ops.conv(ops.View.from_nchw(g(xs)), ops.direct_weight(g(ws)), 3, 64, mfma=False, stride=2, pad=0, bias=g(bs), res=ops.View.from_nchw(g(rs)),
+             out_scale=0.5, out=o)
+    refs = (F.conv2d(xs, ws, bs, stride=2) + rs) * 0.5
+    assert maxdiff(o.to_nchw(), refs) < 1e-5
+    assert maxdiff(o.stats[..., 0], refs.sum(dim=(2, 3))) < 1e-3 and maxdiff(o.stats[..., 1], (refs * refs).sum(dim=(2, 3))) < 1e-3
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout,ks', [(2, 8, 32, 32, 64, 3), (1, 20, 37, 48, 96, 3), (2, 16, 16, 80, 16, 3), (1, 64, 64, 256, 256, 3),
                                               (1, 33, 9, 8, 24, 3), (2, 16, 16, 64, 128, 1), (1, 5, 7, 36, 40, 1), (1, 64, 64, 256, 768, 1)])
 def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
