@@ -8,7 +8,8 @@
 A "step" is one pass of the hot path over one batch of synthetic slices: the complete 4-step
 dual-generator reverse sampling (4 x [G1 -> G2 -> posterior]) of B 256x256 slices per GPU (BASELINE
 config 2 shapes: nf=64, ch_mult 1-2-4, 2 res blocks, nz=100; random-init weights - no trained weights
-exist offline; noise drawn on the device).  value = slices/s over ALL ranks = N*B*K / max-over-
+exist offline; noise drawn on the device; like mudiff_hip.sampling.sample_from_model, the captured
+sampler computes what depends on the condition images alone once per slice, not once per reverse step).  value = slices/s over ALL ranks = N*B*K / max-over-
 ranks wall time, inputs resident in HBM, fp32 in / fp32 out.
 
 One JSON line on rank 0, with

@@ -338,9 +338,19 @@ class ConvBlock(nn.Module, _Prepared):
     def _prepare(self):
         return dict(c1=ConvParam(self.conv1), c2=ConvParam(self.conv2))
 
-    def run(self, x: View, style_out, out: View = None, arena=None):
+    def run(self, x: View, style_out, out: View = None, arena=None, cache: dict = None):
+        """`cache` (a dict owned by the generator's loop cache): conv1(x) and its GroupNorm sums depend on the condition image
+        alone, so inside a sampling loop they are computed once; only the style-dependent half is redone."""
         p = self.prepared()
-        h = p['c1'](x, arena=arena)
+        if cache is not None and 'h' in cache:
+            h = cache['h']
+            if arena is not None:
+                h.stats = arena.take(h.B, h.C)
+                h.stats.copy_(cache['stats'])
+        else:
+            h = p['c1'](x, arena=arena)
+            if cache is not None and h.stats is not None:
+                cache.update(h=h, stats=h.stats.clone())
         sc, sh = self.group_norm.scale_shift(h, style_out)
         return p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU), out=out)
 

@@ -74,6 +74,7 @@ def _check_config(config):
 class _NCSNppBase(nn.Module, layerspp._Prepared):
     ADAPTIVE = False
     N_COND = 3          # 2 in ncsnpp_generator_adagn_feat_healthy.py
+    _loop_cache = None
 
     def __init__(self, config):
         super().__init__()
@@ -202,6 +203,16 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         self.z_transform = nn.Sequential(*mapping_layers)
 
     # ------------------------------------------------------------------------------------------
+    def begin_loop_cache(self):
+        """Opt-in for a sampling loop (mudiff_hip.sampling): between begin_loop_cache() and end_loop_cache() the CONDITION
+        images are the caller's loop invariants, so everything that depends on them alone - G1's three condition feature
+        blocks (reference :318-328 recomputes them at every reverse step) - is computed by the first forward and kept in
+        the U-Net concatenation buffer for the following ones.  Outputs are unchanged.  Plain forward calls never cache."""
+        self._loop_cache = {}
+
+    def end_loop_cache(self):
+        self._loop_cache = None
+
     def _prepare(self):
         """Batched small-dense weights: every GroupNorm_{0,1}.style of the ResBlocks in one matrix
         (input zemb), every Dense_0 in another (input silu(temb))."""
@@ -427,9 +438,25 @@ class _G1(_NCSNppBase):
             nf = self.nf
             arena = ops.StatsArena(xv.device)
             trunk, bufs = self._make_buffers(B, H, W, xv.device, arena)
+            feats = [e for e in self._plan if e['kind'] == 'feat']
+            lc = self._loop_cache
+            key = (B, H, W) + tuple((c.data_ptr(), c._version) for c in conds)
+            reuse = lc is not None and lc.get('key') == key
+            if reuse:
+                # the last concatenation buffer [h | x_feat | c1f | c2f | c3f] is the cached one: the condition slots (and
+                # their GroupNorm sums) are already there; x_feat and h are rewritten below / by the up path
+                buf = lc['buf']
+                buf.stats = arena.take(B, buf.C)
+                c0 = bufs[-1][1] + nf
+                buf.stats[:, c0:].copy_(lc['stats'])
+                bufs[-1] = (buf, bufs[-1][1], bufs[-1][2])
             hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
-            for j, (e, img) in enumerate(zip([e for e in self._plan if e['kind'] == 'feat'], imgs)):
+            for j, (e, img) in enumerate(zip(feats, imgs)):
+                if reuse and j > 0:
+                    continue
                 mods[e['idx']].run(img, out=hs0.slice(j * nf, nf), arena=arena)
+            if lc is not None and not reuse:
+                lc.update(key=key, buf=bufs[-1][0], stats=bufs[-1][0].stats[:, bufs[-1][1] + nf:].clone())
             return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)
 
 
@@ -454,8 +481,15 @@ class _G2(_NCSNppBase):
             mods[e_feat['idx']].run(xv, out=hs0.slice(0, nf), arena=arena)
             ada_styles = ops.dense(pseudo_weight, p['ada_w'], p['ada_b'])                                  # [B, nc*2nf]
             cat = View.empty(B, H, W, nc * nf, dev)
+            lc = self._loop_cache
+            if lc is not None:      # inside a sampling loop: conv1 of the condition blocks is a loop invariant (begin_loop_cache)
+                key = (B, H, W) + tuple((c.data_ptr(), c._version) for c in conds)
+                if lc.get('key') != key:
+                    lc.clear()
+                    lc.update(key=key, ada=[{} for _ in e_ada])
             for j, (e, c) in enumerate(zip(e_ada, conds)):
-                mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf), arena=arena)
+                mods[e['idx']].run(View.from_nchw(c.detach()), ada_styles[:, j * 2 * nf:(j + 1) * 2 * nf], out=cat.slice(j * nf, nf), arena=arena,
+                                   cache=lc['ada'][j] if lc is not None else None)
             # att1 gates already multiplied by the feature they gate: sigmoid(conv(cat)) * c_i (pair k gates c_k: c12 -> c1,
             # c23 -> c2, c31 -> c3, reference :778,783,787); att2 gates: plain sigmoid
             npair = len(self._pairs)

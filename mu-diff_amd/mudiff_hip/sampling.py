@@ -137,17 +137,24 @@ def sample_from_model(coefficients, generator1, cond1, generator2, cond2, cond3,
     zs / noises: optional per-step injected draws (zs[k], noises[k] for the k-th executed step)."""
     x = x_init
     steps = []
-    with torch.no_grad():
-        for k, i in enumerate(reversed(range(n_time))):
-            t = torch.full((x.size(0),), i, dtype=torch.int64, device=x.device)
-            latent_z = torch.randn(x.size(0), opt.nz, device=x.device) if zs is None else zs[k]
-            x_0_1 = generator1(x, cond1, cond2, cond3, t, latent_z)
-            x_0_2 = generator2(x, cond1, cond2, cond3, t, latent_z, x_0_1[:, [0], :])
-            x_new = sample_posterior_combine(coefficients, x_0_1[:, [0], :], x_0_2[:, [0], :], x, t,
-                                             None if noises is None else noises[k])
-            if return_steps:
-                steps.append((x_0_1, x_0_2, x_new))
-            x = x_new.detach()
+    gens = [g_ for g_ in (generator1, generator2) if hasattr(g_, 'begin_loop_cache')]
+    for g_ in gens:          # the conditions are loop invariants: what depends on them alone is computed by the first step only
+        g_.begin_loop_cache()
+    try:
+        with torch.no_grad():
+            for k, i in enumerate(reversed(range(n_time))):
+                t = torch.full((x.size(0),), i, dtype=torch.int64, device=x.device)
+                latent_z = torch.randn(x.size(0), opt.nz, device=x.device) if zs is None else zs[k]
+                x_0_1 = generator1(x, cond1, cond2, cond3, t, latent_z)
+                x_0_2 = generator2(x, cond1, cond2, cond3, t, latent_z, x_0_1[:, [0], :])
+                x_new = sample_posterior_combine(coefficients, x_0_1[:, [0], :], x_0_2[:, [0], :], x, t,
+                                                 None if noises is None else noises[k])
+                if return_steps:
+                    steps.append((x_0_1, x_0_2, x_new))
+                x = x_new.detach()
+    finally:
+        for g_ in gens:
+            g_.end_loop_cache()
     return (x, steps) if return_steps else x
 
 
@@ -176,6 +183,10 @@ class GraphSampler:
         self.x_new = sample_posterior_combine(self.coef, x01, x02, self.x, self.t, self.noise)
 
     def _capture(self, warmup):
+        """Two graphs: the FIRST reverse step (fills the generators' loop caches: everything that depends on the condition
+        images alone) and every LATER step (reuses them).  Both are captured with the caches bound to the same static
+        buffers, in one memory pool."""
+        gens = [g_ for g_ in (self.g1, self.g2) if hasattr(g_, 'begin_loop_cache')]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -183,9 +194,21 @@ class GraphSampler:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self._step()
+        for g_ in gens:
+            g_.begin_loop_cache()
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self._step()
+            self._first_out = (self.x01, self.x02, self.x_new)
+            self.graph_rest = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph_rest, pool=self.graph.pool()):
+                self._step()
+            self._rest_out = (self.x01, self.x02, self.x_new)
+            self._caches = [g_._loop_cache for g_ in gens]      # keep the cached buffers alive with the graphs
+        finally:
+            for g_ in gens:
+                g_.end_loop_cache()
 
     def sample(self, cond1, cond2, cond3, x_init, n_time, zs=None, noises=None, return_steps=False):
         self.c1.copy_(cond1); self.c2.copy_(cond2); self.c3.copy_(cond3)
@@ -198,9 +221,14 @@ class GraphSampler:
                 self.noise.normal_()
             else:
                 self.z.copy_(zs[k]); self.noise.copy_(noises[k])
-            self.graph.replay()
+            if k == 0:
+                self.graph.replay()
+                x01, x02, x_new = self._first_out
+            else:
+                self.graph_rest.replay()
+                x01, x02, x_new = self._rest_out
             if return_steps:
-                steps.append((self.x01.clone(), self.x02.clone(), self.x_new.clone()))
-            self.x.copy_(self.x_new)
+                steps.append((x01.clone(), x02.clone(), x_new.clone()))
+            self.x.copy_(x_new)
         out = self.x.clone()
         return (out, steps) if return_steps else out

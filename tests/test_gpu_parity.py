@@ -471,6 +471,35 @@ def test_graph_sampler_matches_eager_and_batches():
     assert maxdiff(eager, ref) <= 1e-3
 
 
+def test_loop_cache_changes_nothing():
+    """sample_from_model / GraphSampler hoist what depends on the condition images alone out of the reverse loop
+    (begin_loop_cache): same images as plain per-step forward calls (which never cache), and a second sampling run with OTHER
+    conditions must not see the first run's cache."""
+    ops, S, *_ = _imports()
+    cfg = O.default_config(**SMALL_CFGS['s32'])
+    g1, g2 = _build(cfg)
+    coef = S.Posterior_Coefficients(cfg, DEV)
+    x_init, zs, noises = sampler_inputs(cfg, 2)
+    zs, noises = [g(z) for z in zs], [g(n) for n in noises]
+    for seed in (1, 2):
+        gen = torch.Generator().manual_seed(seed)
+        conds = [g(torch.tanh(torch.randn(2, 1, 32, 32, generator=gen))) for _ in range(3)]
+        cached = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], 4, g(x_init), None, cfg, zs=zs, noises=noises)
+        assert g1._loop_cache is None and g2._loop_cache is None
+        x = g(x_init)
+        for k, i in enumerate(reversed(range(4))):
+            t = torch.full((2,), i, dtype=torch.int64, device=DEV)
+            y1 = g1(x, *conds, t, zs[k])
+            y2 = g2(x, *conds, t, zs[k], y1)
+            x = S.sample_posterior_combine(coef, y1, y2, x, t, noises[k])
+        assert maxdiff(cached, x) <= 1e-4
+    sampler = S.GraphSampler(coef, g1, g2, cfg, 2, 32, 32, DEV)
+    assert maxdiff(sampler.sample(*conds, g(x_init), 4, zs=zs, noises=noises), x) <= 1e-4
+    other = [torch.flip(c, dims=(3,)) for c in conds]
+    want = S.sample_from_model(coef, g1, other[0], g2, other[1], other[2], 4, g(x_init), None, cfg, zs=zs, noises=noises)
+    assert maxdiff(sampler.sample(*other, g(x_init), 4, zs=zs, noises=noises), want) <= 1e-4
+
+
 def test_cpu_tensors_fail_loudly():
     *_, NCSNpp, _ = _imports()
     import mudiff_hip
