@@ -11,8 +11,9 @@ follows (paths relative to the reference checkout).  Layout is the reference's: 
 Pinning: the reference has no tests and no golden vectors.  The oracle is
 pinned by outputs of the reference itself run in the build container:
 ``tests/golden/make_golden.py`` imports the reference's ``backbones`` (safe-import recipe,
-SURVEY.md section 8c), compares every function here against it (128 comparisons, all bit-exact
-on torch 2.10 CPU) and stores the reference's outputs as fixtures under ``tests/golden/``,
+SURVEY.md section 8c), compares every function here against it (about 230 comparisons - schedules, posterior, FIR,
+blocks, small and full-size models, 13 alternate configurations, critic, uncertainty map, volume-pipeline pieces - all
+bit-exact on torch 2.10 CPU) and stores the reference's outputs as fixtures under ``tests/golden/``,
 which ``tests/test_oracle_golden.py`` re-checks on every CPU run (the reference itself never
 travels to the GPU box).
 Third-party arithmetic (ATen CPU conv / group_norm / softmax) is whatever torch build is
