@@ -1,4 +1,5 @@
-"""Phase breakdown of the 3x3 conv kernel from in-kernel cycle stamps (needs the instrumented build scripts/exp/libstamp.so)."""
+"""Phase breakdown of the 3x3 conv kernel from in-kernel cycle stamps.  Needs the instrumented build:
+    python scripts/build_stamp_lib.py && MUDIFF_HIP_LIB=scripts/exp/libstamp.so python scripts/stamp_conv.py [batch]"""
 import ctypes, sys, math
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/mu-diff_amd')
 import numpy as np, torch
