@@ -876,7 +876,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
     if (blocks2 >= 512 && a.H >= 8) return cm_launch<3, 2>(a, s);
     return cm_launch<3, 1>(a, s);
   }
-  const int64_t hw = (int64_t)a.H * a.W;
-  if (mud_cdiv(hw, 256) * ntiles * a.B >= 512) return cm_launch<1, 2>(a, s);
+  // 1x1 GEMMs: 128-pixel tiles (MT = 1) beat 256-pixel tiles (MT = 2) by 5-8 % on every skip-conv / NIN shape at batch 16
+  // (scripts/bench_conv.py with MUD_CONV_MT=1/2) - these launches are HBM-bound and the smaller tile keeps more of them in flight
   return cm_launch<1, 1>(a, s);
 }
