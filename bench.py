@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - MU-Diff reverse-diffusion sampling throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--total-slices M] [--sweep 1,2,4,8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -9,18 +9,37 @@ A "step" is one pass of the hot path over one batch of synthetic slices: the com
 dual-generator reverse sampling (4 x [G1 -> G2 -> posterior]) of B 256x256 slices per GPU (BASELINE
 config 2 shapes: nf=64, ch_mult 1-2-4, 2 res blocks, nz=100; random-init weights - no trained weights
 exist offline; noise drawn on the device; like mudiff_hip.sampling.sample_from_model, the captured
-sampler computes what depends on the condition images alone once per slice, not once per reverse step).  value = slices/s over ALL ranks = N*B*K / max-over-
-ranks wall time, inputs resident in HBM, fp32 in / fp32 out.
+sampler computes what depends on the condition images alone once per slice, not once per reverse step).
+value = slices/s over ALL ranks = slices sampled / max-over-ranks wall time, inputs resident in HBM, fp32 in /
+fp32 out.
+
+Ranks.  One process per GPU.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a
+launcher: it starts N fresh rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+MASTER_PORT set) before it makes any GPU call, relays rank 0's JSON line and exits non-zero if any rank fails
+(the reference's analogue: engine/train.py:1454-1470).  Under torch.distributed.run the ranks already exist and
+WORLD_SIZE must equal --gpus.
+
+Scaling.  Default: weak (B slices per GPU per step, so N GPUs sample N*B slices per step).  `--total-slices M`:
+strong - a step is one pass over M slices sharded contiguously over the ranks (mudiff_hip.distributed.shard_range;
+SURVEY.md section 8(d) item 4, M = 512 there).  `--sweep 1,2,4,8`: runs the strong-scaling bench at every listed GPU
+count that fits the visible devices and prints ONE line {n: slices/s} with the CPU baseline beside it.
 
 One JSON line on rank 0, with
-  roofline      the dominant kernel (3x3 implicit-GEMM conv on split-bf16 MFMA): algorithmic FLOPs /
-                per-launch HIP-event time, measured in an instrumented pass of the same workload;
-  cpu_baseline  the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's cores on
-                a bounded sample (1 slice), rank 0, N=1 only.
+  roofline        the dominant kernel (3x3 implicit-GEMM conv on split-bf16 MFMA): algorithmic FLOPs /
+                  per-launch HIP-event time, measured in an instrumented pass of the same workload;
+  cpu_baseline    the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's cores on
+                  a bounded sample (1 slice), rank 0, N=1 only;
+  parity          BASELINE config 2 with the committed reference-made fixture (tests/golden/full_cfg2.npz: the
+                  reference's demo images, injected draws) through the same captured sampler: per-step max-abs,
+                  dPSNR, dSSIM against the reference's own outputs (N=1 only);
+  batch1/batch32  the same path at 1 (config 2 read literally) and 32 (config 3) slices per step;
+  pcie_inclusive  H2D of the three condition batches + sampling + D2H of the result inside the timed region.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,27 +48,160 @@ for _p in (REPO, os.path.join(REPO, 'mu-diff_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not touch the GPU)
 
-FLOP_PER_SLICE = 3456.4e9        # 4 x (378.87 + 485.24) GFLOP, B=1
+FLOP_PER_SLICE = 3456.4e9        # 4 x (378.87 + 485.24) GFLOP, B=1, the reference's graph
 FUSED_BYTES_PER_SLICE = 19.9e9   # algorithmic HBM bytes, fully fused ideal
 PEAK_BF16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+METRIC = '256x256 slices/sec (4-step dual-gen reverse)'
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '16')), help='slices per GPU per step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '16')), help='slices per GPU per captured reverse step')
+    ap.add_argument('--total-slices', type=int, default=0, help='strong scaling: a step is one pass over this many slices sharded over the ranks')
+    ap.add_argument('--sweep', default='', help='comma-separated GPU counts, e.g. 1,2,4,8: strong-scaling curve + CPU baseline in one line')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    return ap.parse_args()
+    ap.add_argument('--no-extras', action='store_true', help='skip the parity / batch1 / batch32 / pcie legs')
+    return ap.parse_args(argv)
 
 
+def log(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher (no GPU call happens in this process)
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def last_json_line(text):
+    for ln in reversed(text.strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith('{') and ln.endswith('}'):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def launch_ranks(n, argv, extra_env=None, timeout=None):
+    """Start n rank processes of this script (one per GPU) and wait.  -> (returncode, rank-0 stdout).
+    Any rank failing terminates the others (exactly the PIDs started here) and the result is non-zero."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    t0 = time.time()
+    rc = 0
+    live = set(range(n))
+    out0 = None
+    try:
+        while live:
+            for r in sorted(live):
+                if r == 0 and out0 is None and procs[0].poll() is not None:
+                    out0 = procs[0].stdout.read()
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    log(f'rank {r} exited with code {code}; stopping the other ranks')
+                    for o in sorted(live):
+                        procs[o].terminate()
+            if timeout is not None and time.time() - t0 > timeout:
+                rc = rc or 124
+                log(f'launcher timeout after {timeout} s; stopping the ranks')
+                for o in sorted(live):
+                    procs[o].terminate()
+                timeout = None
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    if out0 is None:
+        out0 = procs[0].stdout.read() or ''
+    return rc, out0
+
+
+def visible_gpus():
+    n = os.environ.get('MUDIFF_BENCH_VISIBLE_GPUS')      # test hook; device_count() does not initialise the GPU on this image
+    return int(n) if n else torch.cuda.device_count()
+
+
+def run_sweep(a, argv):
+    """Strong-scaling curve: the same M slices at every GPU count that fits, CPU baseline beside it, ONE line."""
+    counts = [int(c) for c in a.sweep.split(',') if c.strip()]
+    have = visible_gpus()
+    total = a.total_slices or 512
+    clean, skip = [], False                                # the caller's flags minus the ones each run sets itself
+    for x in argv:
+        if skip:
+            skip = False
+        elif x in ('--sweep', '--gpus', '--total-slices'):
+            skip = True
+        elif not x.startswith(('--sweep=', '--gpus=', '--total-slices=')):
+            clean.append(x)
+    curve, lines, skipped, rc_all = {}, {}, [], 0
+    for n in counts:
+        if n > have:
+            skipped.append(n)
+            continue
+        args = clean + ['--gpus', str(n), '--total-slices', str(total), '--no-extras']
+        if n != counts[0] or a.no_cpu_baseline:
+            args.append('--no-cpu-baseline')
+        if n != counts[0]:
+            args.append('--no-roofline')
+        log(f'sweep: {n} GPU(s) ...')
+        if n == 1:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), *args], stdout=subprocess.PIPE, text=True,
+                               env={k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')})
+            rc, out = p.returncode, p.stdout
+        else:
+            rc, out = launch_ranks(n, args)
+        line = last_json_line(out or '')
+        if rc != 0 or line is None:
+            rc_all = rc_all or rc or 1
+            log(f'sweep: the {n}-GPU run failed (rc {rc})')
+            continue
+        curve[str(n)] = line['value']
+        lines[str(n)] = line
+    first = lines.get(str(counts[0])) or (next(iter(lines.values())) if lines else {})
+    out = {'metric': METRIC, 'unit': 'slices/s', 'higher_is_better': True, 'scaling': 'strong', 'data': 'synthetic',
+           'total_slices': total, 'slices_per_s_by_gpus': curve,
+           'value': max(curve.values()) if curve else None, 'n_gpus': max((int(k) for k in curve), default=0),
+           'ms_per_step_by_gpus': {k: v['ms_per_step'] for k, v in lines.items()},
+           'ranks_seen_by_gpus': {k: v.get('ranks_seen') for k, v in lines.items()},
+           'skipped_gpu_counts': skipped, 'visible_gpus': have, 'steps': a.steps, 'warmup': a.warmup,
+           'dtype': first.get('dtype'), 'config': first.get('config'), 'vs_baseline': None,
+           'cpu_baseline': first.get('cpu_baseline'), 'roofline': first.get('roofline')}
+    print(json.dumps(out), flush=True)
+    return rc_all
+
+
+# ---------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------
 def bench_config():
     """BASELINE config 2 (demo.ipynb cell 3 / SURVEY.md section 8): the attribute bag the generators' constructors read."""
     from types import SimpleNamespace
@@ -149,52 +301,188 @@ def cpu_baseline(cfg):
                        f'{dt:.2f} s; torch {torch.__version__} CPU fp32')
 
 
+def csrc_digest():
+    """Content hash of the kernel sources: ties a committed PMC measurement to the kernels it was taken on (the GPU box has no
+    .git, so `git log -1 -- mu-diff_amd/csrc` is not available there)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(REPO, 'mu-diff_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(REPO, 'mu-diff_amd', 'csrc', '*.h'))):
+        with open(fn, 'rb') as f:
+            h.update(os.path.basename(fn).encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profiles():
-    """HBM bytes per launch of the dominant kernel from the latest committed PMC passes (profiles/rNN_*_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, gfx950 correction applied).  rocprofv3 cannot run
-    inside the timed process, so the committed measurement is reported, or null when there is none."""
+    """-> (HBM bytes per launch of the dominant kernel, source file) from the latest committed PMC passes
+    (profiles/rNN_*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command in separate passes, gfx950
+    correction applied).  rocprofv3 cannot run inside the timed process, so a committed measurement is reported - and only
+    when it was taken on the kernel sources of this tree (`csrc_digest` recorded in the file); otherwise null."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_traffic.json')))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
-        return json.load(f).get('dominant_hbm_bytes_per_launch')
+        d = json.load(f)
+    src = os.path.relpath(files[-1], REPO)
+    if d.get('csrc_digest') != csrc_digest():
+        return None, f'{src} is stale (taken on other kernel sources)'
+    return d.get('dominant_hbm_bytes_per_launch'), src
 
 
-def log(*a):
-    print('[bench]', *a, file=sys.stderr, flush=True)
+# ---------------------------------------------------------------------------------------------------
+# reference-made fixture of BASELINE config 2 (tests/golden/full_cfg2.npz) through the captured sampler
+# ---------------------------------------------------------------------------------------------------
+def _demo_cond(u8):
+    """demo.ipynb cell 4 of the reference: percentile-1/99 clip over non-zero pixels, min-max, (x-0.5)/0.5, rot90(k=-1)."""
+    import numpy as np
+    img = np.asarray(u8)
+    low, high = np.percentile(img[img > 0], [1, 99])
+    img = np.clip(img, low, high)
+    img = (img - img.min()) / (img.max() - img.min())
+    img = (img - 0.5) / 0.5
+    return torch.rot90(torch.tensor(img, dtype=torch.float32)[None, None], k=-1, dims=(2, 3)).contiguous()
 
 
-def main():
-    a = parse()
+def parity_leg(cfg, dev):
+    """The reference's own run of config 2 (its demo JPEGs as conditions, seeded weights, recorded x_init / z / noise draws;
+    tests/golden/make_golden.py) against the HIP path through GraphSampler: what the -m gpu parity test checks, in the line."""
+    import numpy as np
+    from backbones.ncsnpp_generator_adagn_feat import NCSNpp, NCSNpp_adaptive
+    from mudiff_hip import driver, sampling as S
+    from mudiff_hip.weights import seeded_state_dict
+    gold = os.path.join(REPO, 'tests', 'golden')
+    with np.load(os.path.join(gold, 'full_cfg2.npz'), allow_pickle=False) as z:
+        ref = {k: torch.from_numpy(z[k]) for k in z.files}
+    with np.load(os.path.join(gold, 'demo_inputs_u8.npz'), allow_pickle=False) as z:
+        conds = [_demo_cond(z[n]).to(dev) for n in ('flair', 't2', 't1')]
+        target = _demo_cond(z['t1ce'])[0, 0].numpy()
+    g1, g2 = NCSNpp(cfg), NCSNpp_adaptive(cfg)
+    g1.load_state_dict(seeded_state_dict(g1, 'g1', 1234, cfg.fourier_scale))
+    g2.load_state_dict(seeded_state_dict(g2, 'g2', 1234, cfg.fourier_scale))
+    g1, g2 = g1.to(dev).eval(), g2.to(dev).eval()
+    H = cfg.image_size
+    gen = torch.Generator().manual_seed(42)                       # the draws of tests/golden/make_golden.py (tests/helpers.py::sampler_inputs)
+    x_init = torch.randn(1, 1, H, H, generator=gen)
+    st = torch.get_rng_state()
+    torch.manual_seed(43)
+    zs, noises = [], []
+    for _ in range(cfg.num_timesteps):
+        zs.append(torch.randn(1, cfg.nz))
+        noises.append(torch.randn(1, 1, H, H))
+    torch.set_rng_state(st)
+    sampler = S.GraphSampler(S.Posterior_Coefficients(cfg, dev), g1, g2, cfg, 1, H, H, dev)
+    x, steps = sampler.sample(*conds, x_init.to(dev), cfg.num_timesteps, zs=[t.to(dev) for t in zs], noises=[t.to(dev) for t in noises],
+                              return_steps=True)
+    per_step = []
+    for k, stp in enumerate(steps):
+        per_step.append(max(float((v.cpu() - ref[f'step{k}.{nm}']).abs().max()) for nm, v in zip(('x01', 'x02', 'xnew'), stp)))
+    to01 = lambda t: (np.asarray(t, np.float64) + 1) / 2          # noqa: E731
+    ours, theirs = x.cpu()[0, 0].numpy(), ref[f'step{cfg.num_timesteps - 1}.xnew'][0, 0].numpy()
+    dp = driver.psnr(to01(target), to01(ours)) - driver.psnr(to01(target), to01(theirs))
+    ds = driver.ssim(to01(target), to01(ours)) - driver.ssim(to01(target), to01(theirs))
+    return {'fixture': 'tests/golden/full_cfg2.npz (outputs of the reference itself on its demo images, B=1, injected draws)',
+            'max_abs_per_step': [float(f'{e:.3e}') for e in per_step], 'tolerance': 1e-3, 'dpsnr_db': round(dp, 5), 'dssim': round(ds, 6),
+            'ok': bool(max(per_step) <= 1e-3 and abs(dp) <= 0.05 and abs(ds) <= 0.001)}
+
+
+def timed_batches(sampler_fn, n_iter):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_iter):
+        sampler_fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------------------------------------------
+def dryrun_worker(a, rank, world):
+    """Launcher self-test (tests/test_bench_launcher.py): the rank plumbing of the real worker - env wiring, process
+    group, barrier, MAX-over-ranks timing, ranks_seen, rank-0 line - over gloo on CPU tensors with a stand-in timed region."""
+    import torch.distributed as dist
+    from mudiff_hip.distributed import max_over_ranks, shard_range
+    if os.environ.get('MUDIFF_BENCH_FAIL_RANK') == str(rank):
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group(backend='gloo', init_method='env://')
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    lo, hi = shard_range(a.total_slices, rank, world) if a.total_slices else (rank * a.batch, (rank + 1) * a.batch)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = max_over_ranks(time.perf_counter() - t0, 'cpu')
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, (rank, lo, hi))
+    else:
+        seen = [(rank, lo, hi)]
+    if rank == 0:
+        print(json.dumps({'metric': METRIC, 'dryrun': True, 'n_gpus': world, 'ranks_seen': sorted(s[0] for s in seen),
+                          'shards': [list(s[1:]) for s in sorted(seen)], 'value': round((a.total_slices or world * a.batch) / dt, 3),
+                          'ms_per_step': round(1e3 * dt, 3), 'scaling': 'strong' if a.total_slices else 'weak'}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def worker(a):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch exactly --gpus ranks '
+                         f'(python bench.py --gpus {a.gpus} starts them itself when WORLD_SIZE is unset)')
+    if os.environ.get('MUDIFF_BENCH_DRYRUN') == '1':
+        return dryrun_worker(a, rank, world)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU fallback for the HIP path'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    ranks_seen = [0]
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)   # nccl == RCCL on ROCm
+        assert dist.get_world_size() == a.gpus
+        got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks_seen = sorted(int(t.item()) for t in got)
+        assert ranks_seen == list(range(world)), ranks_seen
 
     from mudiff_hip import ops, sampling as S
+    from mudiff_hip.distributed import max_over_ranks, shard_range
     cfg = bench_config()
     B, K, W = a.batch, a.steps, a.warmup
     H = cfg.image_size
     g1, g2 = build_models(cfg, dev, rank, world)
     coef = S.Posterior_Coefficients(cfg, dev)
-    c1, c2, c3 = synthetic_batch(cfg, B, dev, seed=100 + rank)     # each rank owns its shard of slices
+    strong = a.total_slices > 0
+    if strong:
+        lo, hi = shard_range(a.total_slices, rank, world)         # this rank's contiguous shard of the M slices
+        n_local = hi - lo
+        nb = (n_local + B - 1) // B
+        conds = synthetic_batch(cfg, max(nb * B, B), dev, seed=100 + rank)     # resident in HBM; the tail batch is padded
+        batches = [tuple(c[i * B:(i + 1) * B] for c in conds) for i in range(nb)]
+    else:
+        n_local = B
+        batches = [tuple(synthetic_batch(cfg, B, dev, seed=100 + rank))]       # each rank owns its shard of slices
+    c1, c2, c3 = batches[0] if batches else synthetic_batch(cfg, B, dev, seed=100 + rank)
     x_init = torch.randn(B, 1, H, H, device=dev)
 
-    log(f'models built, rank {rank}/{world}, B={B}')
+    log(f'models built, rank {rank}/{world}, B={B}' + (f', slices [{lo}, {hi}) of {a.total_slices}' if strong else ''))
     if a.no_graph:
-        def one_step():
-            return S.sample_from_model(coef, g1, c1, g2, c2, c3, cfg.num_timesteps, x_init, None, cfg)
+        def one_batch(cs):
+            return S.sample_from_model(coef, g1, cs[0], g2, cs[1], cs[2], cfg.num_timesteps, x_init, None, cfg)
     else:
         sampler = S.GraphSampler(coef, g1, g2, cfg, B, H, H, dev)
 
-        def one_step():
-            return sampler.sample(c1, c2, c3, x_init, cfg.num_timesteps)
+        def one_batch(cs):
+            return sampler.sample(cs[0], cs[1], cs[2], x_init, cfg.num_timesteps)
+
+    def one_step():
+        out = None
+        for cs in batches:
+            out = one_batch(cs)
+        return out
 
     def barrier():
         if world > 1:
@@ -203,6 +491,7 @@ def main():
         torch.cuda.synchronize()
 
     log('sampler ready (hipGraph captured)' if not a.no_graph else 'eager mode')
+    out = None
     for _ in range(W):
         out = one_step()
     barrier()
@@ -212,25 +501,25 @@ def main():
         out = one_step()
     barrier()
     dt = time.perf_counter() - t0
-    assert torch.isfinite(out).all()
-    from mudiff_hip.distributed import max_over_ranks
+    assert out is None or torch.isfinite(out).all()
     dt = max_over_ranks(dt, dev)
 
-    slices = world * B * K
+    slices = (a.total_slices if strong else world * B) * K
     value = slices / dt
     log(f'timed region: {dt:.3f} s for {slices} slices -> {value:.2f} slices/s')
+    workload = (f'BASELINE config 2 shapes: 4-step dual-generator sampling, 256x256, nf=64, ch_mult 1-2-4, '
+                + (f'{a.total_slices} slices per step sharded contiguously over {world} GPU(s) in batches of {B}'
+                   if strong else f'{B} slices per GPU per step, batch-sharded over {world} GPU(s)') + ', weights replicated')
     line = {
-        'metric': '256x256 slices/sec (4-step dual-gen reverse)', 'value': round(value, 3), 'unit': 'slices/s',
+        'metric': METRIC, 'value': round(value, 3), 'unit': 'slices/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * dt / K, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (convs/attention: bf16 hi+lo split MFMA x3, fp32 accumulate)',
-        'data': 'synthetic',
-        'config': {'workload': f'BASELINE config 2 shapes: 4-step dual-generator sampling, 256x256, nf=64, ch_mult 1-2-4, '
-                               f'{B} slices per GPU per step, batch-sharded over {world} GPU(s), weights replicated',
-                   'slices_per_gpu_per_step': B, 'hipgraph': not a.no_graph},
-        'end_to_end': {'fp32_flop_frac': round(value * FLOP_PER_SLICE / 1e12 / world / PEAK_FP32_TFLOPS, 4),
-                       'bf16x3_issued_frac': round(3 * value * FLOP_PER_SLICE / 1e12 / world / PEAK_BF16_TFLOPS, 4),
-                       'fused_hbm_frac': round(value * FUSED_BYTES_PER_SLICE / 1e9 / world / PEAK_HBM_GBS, 4)},
+        'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (convs/attention: bf16 hi+lo split MFMA x3, fp32 accumulate)',
+        'data': 'synthetic', 'ranks_seen': ranks_seen,
+        'config': {'workload': workload, 'slices_per_gpu_per_step': n_local, 'batch': B, 'hipgraph': not a.no_graph,
+                   **({'total_slices': a.total_slices} if strong else {})},
     }
+    flop_per_slice = FLOP_PER_SLICE
 
     if rank == 0 and not a.no_roofline:
         # instrumented eager pass of the same workload: HIP events around every launch of the dominant kernel
@@ -242,9 +531,10 @@ def main():
         k = prof.get('conv_mfma_k3')
         if k:
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
+            traffic, tsrc = traffic_from_profiles()
             line['roofline'] = {'kernel': 'k_conv_mfma<3> (3x3 implicit GEMM, split-bf16 MFMA)', 'bound': 'mfma',
                                 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                                'traffic': traffic_from_profiles(),
+                                'traffic': traffic, 'traffic_source': tsrc,
                                 'launches': k['n'], 'avg_launch_us': round(1e3 * k['ms'] / k['n'], 2),
                                 'algorithmic_gflop_per_launch': round(k['flops'] / k['n'] / 1e9, 3),
                                 'algorithmic_bytes_per_launch': int(k['bytes'] / k['n']),
@@ -252,19 +542,41 @@ def main():
                                 'vs_fp32_peak_157.3': round(ach / PEAK_FP32_TFLOPS, 3),
                                 'share_of_gpu_time': round(k['ms'] / sum(v['ms'] for v in prof.values()), 3)}
             line['kernel_time_ms_per_batch'] = {n: round(v['ms'], 3) for n, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
-    if rank == 0 and world == 1 and B != 1 and not a.no_roofline:
-        # latency case of BASELINE config 2 read literally (batch = 1): one slice at a time through its own hipGraph
-        s1 = S.GraphSampler(coef, g1, g2, cfg, 1, H, H, dev)
-        x1 = torch.randn(1, 1, H, H, device=dev)
-        for _ in range(2):
-            s1.sample(c1[:1], c2[:1], c3[:1], x1, cfg.num_timesteps)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(6):
-            s1.sample(c1[:1], c2[:1], c3[:1], x1, cfg.num_timesteps)
-        torch.cuda.synchronize()
-        line['batch1'] = {'slices_per_s': round(6 / (time.perf_counter() - t1), 2), 'note': 'same path, 1 slice per step (latency case)'}
-        del s1
+            # FLOPs the path actually issues per slice (the loop cache skips what depends on the condition images alone)
+            flop_per_slice = sum(v['flops'] for v in prof.values()) / B
+    per_gpu = value / world
+    line['end_to_end'] = {'flop_per_slice_issued': round(flop_per_slice / 1e9, 1), 'flop_per_slice_reference_graph': round(FLOP_PER_SLICE / 1e9, 1),
+                          'fp32_flop_frac': round(per_gpu * flop_per_slice / 1e12 / PEAK_FP32_TFLOPS, 4),
+                          'bf16x3_issued_frac': round(3 * per_gpu * flop_per_slice / 1e12 / PEAK_BF16_TFLOPS, 4),
+                          'fused_hbm_frac': round(per_gpu * FUSED_BYTES_PER_SLICE / 1e9 / PEAK_HBM_GBS, 4)}
+
+    extras = rank == 0 and world == 1 and not a.no_extras and not a.no_graph
+    if extras:
+        # PCIe-inclusive rate (SURVEY.md section 8(d) "Metric"): H2D of the three condition batches + sampling + D2H of the result
+        hc = [c.cpu().pin_memory() for c in (c1, c2, c3)]
+        hout = torch.empty(B, 1, H, H).pin_memory()
+
+        def pcie_step():
+            d = [c.to(dev, non_blocking=True) for c in hc]
+            hout.copy_(sampler.sample(d[0], d[1], d[2], x_init, cfg.num_timesteps), non_blocking=True)
+        pcie_step()
+        tp = timed_batches(pcie_step, 3)
+        line['pcie_inclusive'] = {'slices_per_s': round(3 * B / tp, 2), 'note': 'pinned host buffers; 3 x H2D + sample + D2H per batch inside the timed region'}
+        del sampler
+        # latency case of BASELINE config 2 read literally (batch = 1) and config 3's batch of 32, same path, own hipGraphs
+        for nb_, key, iters in ((1, 'batch1', 6), (32, 'batch32', 3)):
+            if nb_ == B:
+                line[key] = {'slices_per_s': line['value'], 'note': 'the headline run'}
+                continue
+            cs = synthetic_batch(cfg, nb_, dev, seed=7)
+            sb = S.GraphSampler(coef, g1, g2, cfg, nb_, H, H, dev)
+            xb = torch.randn(nb_, 1, H, H, device=dev)
+            fn = lambda: sb.sample(cs[0], cs[1], cs[2], xb, cfg.num_timesteps)    # noqa: E731
+            fn(); fn()
+            line[key] = {'slices_per_s': round(iters * nb_ / timed_batches(fn, iters), 2), 'note': f'same path, {nb_} slice(s) per step'}
+            del sb, cs, xb
+        log('parity leg: config 2 fixture through the captured sampler ...')
+        line['parity'] = parity_leg(cfg, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log('timing the CPU oracle on one slice ...')
         line['cpu_baseline'] = cpu_baseline(cfg)
@@ -274,6 +586,24 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse(argv)
+    if a.sweep:
+        sys.exit(run_sweep(a, argv))
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # this process becomes the launcher: it never initialises the GPU
+        rc, out0 = launch_ranks(a.gpus, argv)
+        line = last_json_line(out0 or '')
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        elif rc == 0:
+            rc = 1
+            log('rank 0 printed no JSON line')
+        sys.exit(rc)
+    worker(a)
 
 
 if __name__ == '__main__':

@@ -292,14 +292,13 @@ static int at_splits(int B, int N) {
 template <int C16>
 static int at_launch(const float* qkv, int B, int N, int ld, float scale, float* out, int ldo, float* ws, hipStream_t s) {
   using G = AtGeo<C16>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mud_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)k_attention<C16>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       mud_set_error("mud_attention: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
-    attr_set = true;
   }
   const int ntiles = (int)mud_cdiv(N, 32);
   const int ns = ws ? at_splits(B, N) : 1;

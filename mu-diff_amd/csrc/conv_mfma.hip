@@ -787,15 +787,16 @@ extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, i
 template <int KS, int MT, int WM, int WN, int PRO>
 static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   using G = typename std::conditional<KS == 3, CmGeo<KS, MT, WM, WN>, CmGeoRegB<KS, MT>>::type;
-  const void* kfn = (KS == 3) ? (const void*)k_conv_mfma<KS, MT, WM, WN, PRO> : (const void*)k_conv_mfma_regb<KS, MT, PRO>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const void* kfn;
+  if constexpr (KS == 3) kfn = (const void*)k_conv_mfma<KS, MT, WM, WN, PRO>;      // only the variant that is launched is instantiated
+  else kfn = (const void*)k_conv_mfma_regb<KS, MT, PRO>;
+  static mud_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
-    attr_set = true;
   }
   const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN * WN);
   int tiles_x = 1;
@@ -808,7 +809,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   }
   const int64_t nblocks = tiles * ntiles * a.B;
   MUD_REQUIRE(nblocks <= 0x7fffffff, "mud_conv2d_mfma: grid too large");
-  if (KS == 3)
+  if constexpr (KS == 3)
     hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO>), dim3((unsigned)nblocks), dim3(64 * WM * WN), G::LDS_BYTES, s, a, tiles_x, (int)tiles,
                        ntiles, k16s, (unsigned)nblocks);
   else

@@ -30,6 +30,19 @@ extern "C" void mud_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// Per-device "dynamic LDS size already raised for this kernel" flags: hipFuncSetAttribute acts on the calling thread's
+// current device, so a process that drives several GPUs must repeat it on each.
+struct mud_attr_once {
+  bool done[64] = {};
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;      // benign race: two threads may both set the attribute
+    return true;
+  }
+};
+
 static inline bool mud_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int64_t mud_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

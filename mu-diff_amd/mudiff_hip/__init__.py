@@ -101,14 +101,24 @@ def check(code, what=''):
         raise MudiffHipError(f'{what or "libmudiff_hip"} failed ({code}): {load().mud_last_error().decode()}')
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """torch's current HIP stream on `device` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def require_gpu(*tensors):
+    """All operands of one launch must live on ONE GPU (mudiff_hip.ops launches on that device's current stream whatever
+    the process's current device is)."""
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise MudiffHipError('the MU-Diff HIP path needs tensors on an MI355X (got a CPU tensor); there is no CPU fallback')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise MudiffHipError(f'operands of one launch live on different GPUs ({dev} and {t.device})')
 
 
 def ptr(t):

@@ -129,25 +129,38 @@ def export_and_score(pred_slices, gt_slices, save_dir=None):
 
 
 # ---------------------------------------------------------------------------------------------------
-def sample_slices(args, gen1, gen2, source, batch_size, device, rank=0, world=1, seed=42, progress=None):
+def sample_slices(args, gen1, gen2, source, batch_size, device, rank=0, world=1, seed=42, progress=None, draws=None):
     """Sample this rank's contiguous shard of `source` in batches of `batch_size` through one captured reverse step.
-    -> (lo, predictions [n,H,W] float32 numpy, targets [n,H,W])."""
+    -> (lo, predictions [n,H,W] float32 numpy, targets [n,H,W]).
+    Draws: x_init, z and the posterior noise come from ONE device generator seeded with `seed + rank` (so a run is
+    reproducible from `seed`, and ranks do not repeat each other's streams).  `draws(lo, n) -> (x_init [n,1,H,W],
+    zs [T][n,nz], noises [T][n,1,H,W])` (host tensors, indexed by GLOBAL slice number) injects them instead - parity runs
+    must not depend on how the slices are batched or sharded."""
     from . import sampling as S
     from .distributed import shard_range
     lo, hi = shard_range(len(source), rank, world)
+    device = torch.device(device)
     coef = S.Posterior_Coefficients(args, device)
     preds, gts = [], []
     sampler = None
     gen = torch.Generator(device=device).manual_seed(seed + rank)
+
+    def pad(t, n):      # last partial batch: repeat the last slice up to the fixed graph shape, trimmed afterwards
+        return t if t.shape[0] == batch_size else torch.cat([t, t[-1:].expand(batch_size - n, *t.shape[1:])], 0)
+
     for b0 in range(lo, hi, batch_size):
         c1, c2, c3, y = source.batch(b0, min(b0 + batch_size, hi))
         n = c1.shape[0]
-        if n < batch_size:      # last partial batch: pad by repeating the last slice (fixed graph shape), trim afterwards
-            c1, c2, c3 = (torch.cat([c, c[-1:].expand(batch_size - n, -1, -1, -1)], 0) for c in (c1, c2, c3))
+        c1, c2, c3 = (pad(c, n) for c in (c1, c2, c3))
         if sampler is None:
             sampler = S.GraphSampler(coef, gen1, gen2, args, batch_size, c1.shape[2], c1.shape[3], device)
-        x_init = torch.randn(batch_size, 1, c1.shape[2], c1.shape[3], device=device, generator=gen)
-        out = sampler.sample(c1.to(device), c2.to(device), c3.to(device), x_init, args.num_timesteps)
+        if draws is not None:
+            x_init, zs, noises = draws(b0, n)
+            out = sampler.sample(c1.to(device), c2.to(device), c3.to(device), pad(x_init, n).to(device), args.num_timesteps,
+                                 zs=[pad(z, n).to(device) for z in zs], noises=[pad(e, n).to(device) for e in noises])
+        else:
+            x_init = torch.randn(batch_size, 1, c1.shape[2], c1.shape[3], device=device, generator=gen)
+            out = sampler.sample(c1.to(device), c2.to(device), c3.to(device), x_init, args.num_timesteps, generator=gen)
         preds.append(out[:n, 0].cpu().numpy())
         gts.append(y[:, 0].numpy())
         if progress:

@@ -8,7 +8,7 @@ import math
 import torch
 
 from . import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE, PRO_AFFINE_SILU, PRO_LRELU, PRO_NONE, ConvArgs,  # noqa: F401
-               MudiffHipError, check, load, ptr, require_gpu, stream_ptr)
+               MudiffHipError, check, load, ptr, require_gpu)
 
 
 class StatsArena:
@@ -116,7 +116,18 @@ class _Profile:
 PROFILE = _Profile()
 
 
-def _launch(name, fn, *args, flops=0.0, nbytes=0.0):
+STREAM = object()      # placeholder argument: replaced by the launch device's current HIP stream
+
+
+def _launch(name, dev, fn, *args, flops=0.0, nbytes=0.0):
+    """Enqueue one C-ABI call on the current stream of `dev` - the device the operands live on, which need not be the
+    process's current device (the kernels take raw pointers: a launch on another device would fault or silently run on
+    the wrong GPU)."""
+    idx = torch.cuda.current_device() if dev.index is None else dev.index
+    if idx != torch.cuda.current_device():
+        with torch.cuda.device(idx):
+            return _launch(name, dev, fn, *args, flops=flops, nbytes=nbytes)
+    args = tuple(C.c_void_p(torch.cuda.current_stream().cuda_stream) if a_ is STREAM else a_ for a_ in args)
     if PROFILE.on:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -144,8 +155,8 @@ def posterior_sample(x01, x02, xt, noise, t, coef1, coef2, std_tab, out=None):
         assert x02.shape == xt.shape
     assert x01.shape == xt.shape == noise.shape and t.dtype == torch.int64 and t.numel() == B
     out = torch.empty_like(xt) if out is None else out
-    _launch('posterior_sample', load().mud_posterior_sample, ptr(x01), ptr(x02), ptr(xt), ptr(noise), ptr(t.contiguous()), ptr(coef1), ptr(coef2),
-                                      ptr(std_tab), coef1.numel(), ptr(out), B, per, stream_ptr())
+    _launch('posterior_sample', xt.device, load().mud_posterior_sample, ptr(x01), ptr(x02), ptr(xt), ptr(noise), ptr(t.contiguous()), ptr(coef1), ptr(coef2),
+                                      ptr(std_tab), coef1.numel(), ptr(out), B, per, STREAM)
     return out
 
 
@@ -154,8 +165,8 @@ def q_sample(x, noise, t, toff, a_tab, s_tab):
     x, noise = _f32(x.contiguous()), _f32(noise.contiguous())
     B = x.shape[0]
     out = torch.empty_like(x)
-    _launch('q_sample', load().mud_q_sample, ptr(x), ptr(noise), ptr(t.contiguous()), toff, ptr(a_tab), ptr(s_tab), a_tab.numel(), ptr(out), B,
-                              x[0].numel() if B else 0, stream_ptr())
+    _launch('q_sample', x.device, load().mud_q_sample, ptr(x), ptr(noise), ptr(t.contiguous()), toff, ptr(a_tab), ptr(s_tab), a_tab.numel(), ptr(out), B,
+                              x[0].numel() if B else 0, STREAM)
     return out
 
 
@@ -163,7 +174,7 @@ def timestep_embedding(t, dim, max_positions=10000.0):
     require_gpu(t)
     assert t.dim() == 1 and t.dtype == torch.int64
     out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
-    _launch('timestep_embedding', load().mud_timestep_embedding, ptr(t.contiguous()), ptr(out), t.shape[0], dim, float(max_positions), stream_ptr())
+    _launch('timestep_embedding', t.device, load().mud_timestep_embedding, ptr(t.contiguous()), ptr(out), t.shape[0], dim, float(max_positions), STREAM)
     return out
 
 
@@ -172,7 +183,7 @@ def fourier_embedding(t, W):
     require_gpu(t, W)
     tf, Wf = _f32(t.float().contiguous()), _f32(W.detach().float().contiguous())
     out = torch.empty(tf.shape[0], 2 * Wf.shape[0], device=t.device, dtype=torch.float32)
-    _launch('fourier_embedding', load().mud_fourier_embedding, ptr(tf), ptr(Wf), ptr(out), tf.shape[0], Wf.shape[0], stream_ptr())
+    _launch('fourier_embedding', t.device, load().mud_fourier_embedding, ptr(tf), ptr(Wf), ptr(out), tf.shape[0], Wf.shape[0], STREAM)
     return out
 
 
@@ -180,7 +191,7 @@ def pixel_norm(z):
     require_gpu(z)
     z = _f32(z.contiguous())
     out = torch.empty_like(z)
-    _launch('pixel_norm', load().mud_pixel_norm, ptr(z), ptr(out), z.shape[0], z.shape[1], stream_ptr())
+    _launch('pixel_norm', z.device, load().mud_pixel_norm, ptr(z), ptr(out), z.shape[0], z.shape[1], STREAM)
     return out
 
 
@@ -191,8 +202,8 @@ def dense(x, W, bias, act_in=ACT_NONE, act_out=ACT_NONE):
     B, K = x.shape
     N = W.shape[0]
     out = torch.empty(B, N, device=x.device, dtype=torch.float32)
-    _launch('dense', load().mud_dense, ptr(x), x.stride(0) if B > 1 else K, ptr(W), ptr(bias), ptr(out), N, B, K, N, act_in, act_out,
-                           stream_ptr())
+    _launch('dense', x.device, load().mud_dense, ptr(x), x.stride(0) if B > 1 else K, ptr(W), ptr(bias), ptr(out), N, B, K, N, act_in, act_out,
+                           STREAM)
     return out
 
 
@@ -219,12 +230,12 @@ def gn_scale_shift(x: View, G, gamma=None, beta=None, eps=1e-6):
             assert gamma.shape[0] == x.B and gamma.stride(0) == beta.stride(0)
             bstride = gamma.stride(0)
     if x.stats is not None:      # the producers already accumulated (sum, sumsq): no pass over the tensor
-        _launch('gn_from_sums', lib.mud_gn_scale_shift_from_sums, x.stats_ptr, x.stats.shape[1], x.B, x.C, G, float(HW), eps, ptr(gamma),
-                ptr(beta), bstride, ptr(ss[0]), ptr(ss[1]), x.C, stream_ptr())
+        _launch('gn_from_sums', x.device, lib.mud_gn_scale_shift_from_sums, x.stats_ptr, x.stats.shape[1], x.B, x.C, G, float(HW), eps, ptr(gamma),
+                ptr(beta), bstride, ptr(ss[0]), ptr(ss[1]), x.C, STREAM)
         return ss[0], ss[1]
     ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, G))
-    _launch('gn_scale_shift', lib.mud_gn_scale_shift, x.ptr, x.B, HW, x.C, x.ld, G, eps, ptr(gamma), ptr(beta), bstride, ptr(ss[0]),
-            ptr(ss[1]), x.C, None, ptr(ws), stream_ptr(), nbytes=4.0 * x.npix * x.C)
+    _launch('gn_scale_shift', x.device, lib.mud_gn_scale_shift, x.ptr, x.B, HW, x.C, x.ld, G, eps, ptr(gamma), ptr(beta), bstride, ptr(ss[0]),
+            ptr(ss[1]), x.C, None, ptr(ws), STREAM, nbytes=4.0 * x.npix * x.C)
     return ss[0], ss[1]
 
 
@@ -233,7 +244,7 @@ def channel_mean(x: View):
     HW = x.H * x.W
     ws = _workspace(x.device, lib.mud_gn_ws_bytes(x.B, HW, x.C, x.C))
     out = torch.empty(x.B, x.C, device=x.device, dtype=torch.float32)
-    _launch('channel_mean', lib.mud_channel_mean, x.ptr, x.B, HW, x.C, x.ld, ptr(out), x.C, ptr(ws), stream_ptr(), nbytes=4.0 * x.npix * x.C)
+    _launch('channel_mean', x.device, lib.mud_channel_mean, x.ptr, x.B, HW, x.C, x.ld, ptr(out), x.C, ptr(ws), STREAM, nbytes=4.0 * x.npix * x.C)
     return out
 
 
@@ -244,8 +255,8 @@ def pack_weights(src, s_tap, s_ci, s_co, ks, Cin, Cout, nbatch=1, src_bstride=0,
     require_gpu(src)
     nbytes = lib.mud_packed_weight_bytes(ks, Cin, Cout)
     dst = torch.empty(nbatch, nbytes, device=src.device, dtype=torch.uint8)
-    _launch('pack_weights', lib.mud_pack_weights, C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch,
-                               ptr(dst), stream_ptr())
+    _launch('pack_weights', src.device, lib.mud_pack_weights, C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch,
+                               ptr(dst), STREAM)
     return dst
 
 
@@ -317,7 +328,7 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks     # algorithmic (sub2 issues 4x this)
     nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * (2 if res is not None else 1)) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
-    _launch(name, fn, C.byref(a), stream_ptr(), flops=flops, nbytes=nbytes)
+    _launch(name, x.device, fn, C.byref(a), STREAM, flops=flops, nbytes=nbytes)
     return out
 
 
@@ -333,7 +344,7 @@ def upfirdn2d_planes(x, kernel, up, down, pad):
     Ho = (H * uy + py0 + py1 - kh) // dy + 1
     Wo = (W * ux + px0 + px1 - kw) // dx + 1
     out = torch.empty(N, Cc, Ho, Wo, device=x.device, dtype=torch.float32)
-    _launch('upfirdn2d', load().mud_upfirdn2d, ptr(xin), N * Cc, H, W, ptr(k), kh, kw, ux, uy, dx, dy, px0, px1, py0, py1, ptr(out), stream_ptr())
+    _launch('upfirdn2d', x.device, load().mud_upfirdn2d, ptr(xin), N * Cc, H, W, ptr(k), kh, kw, ux, uy, dx, dy, px0, px1, py0, py1, ptr(out), STREAM)
     return out.to(x.dtype)
 
 
@@ -351,16 +362,16 @@ def fir_nhwc(x: View, kernel2d, up, down, pad, pro=None, want_h=True, want_x=Fal
     if pro is not None:
         sc, sh, mode = pro
         ld = sc.stride(0)
-    _launch('fir_nhwc', load().mud_fir_nhwc, x.ptr, x.B, x.H, x.W, x.C, x.ld, k.ctypes.data_as(C.POINTER(C.c_float)), kh, kw, up, down,
+    _launch('fir_nhwc', x.device, load().mud_fir_nhwc, x.ptr, x.B, x.H, x.W, x.C, x.ld, k.ctypes.data_as(C.POINTER(C.c_float)), kh, kw, up, down,
             pad[0], pad[1], ptr(sc), ptr(sh), ld, mode, oh.ptr if oh else None, oh.ld if oh else 0, ox.ptr if ox else None,
-            ox.ld if ox else 0, stream_ptr(), nbytes=4.0 * x.C * (x.npix + x.B * Ho * Wo * (int(want_h) + int(want_x))))
+            ox.ld if ox else 0, STREAM, nbytes=4.0 * x.C * (x.npix + x.B * Ho * Wo * (int(want_h) + int(want_x))))
     return oh, ox
 
 
 def minibatch_stddev(x: View, group):
     """-> [B] tensor: the critic's minibatch-stddev scalar of every sample's group."""
     out = torch.empty(x.B, device=x.device, dtype=torch.float32)
-    _launch('minibatch_stddev', load().mud_minibatch_stddev, x.ptr, x.B, x.H * x.W, x.C, x.ld, group, ptr(out), stream_ptr())
+    _launch('minibatch_stddev', x.device, load().mud_minibatch_stddev, x.ptr, x.B, x.H * x.W, x.C, x.ld, group, ptr(out), STREAM)
     return out
 
 
@@ -375,27 +386,27 @@ def attention(qkv: View, C_, scale):
     out = View.empty(qkv.B, qkv.H, qkv.W, C_, qkv.device)
     nws = load().mud_attention_ws_bytes(qkv.B, n, C_)        # > 0: few workgroups, the keys are split and merged
     ws = torch.empty(nws // 4, device=qkv.device, dtype=torch.float32) if nws else None
-    _launch('attention', load().mud_attention, qkv.ptr, qkv.B, n, C_, qkv.ld, float(scale), out.ptr, out.ld, ptr(ws) if nws else None,
-            stream_ptr(), flops=4.0 * qkv.B * n * n * C_)
+    _launch('attention', qkv.device, load().mud_attention, qkv.ptr, qkv.B, n, C_, qkv.ld, float(scale), out.ptr, out.ld, ptr(ws) if nws else None,
+            STREAM, flops=4.0 * qkv.B * n * n * C_)
     return out
 
 
 def softmax_rows_(s, n):
     """in-place softmax over the last axis of a contiguous [..., n] tensor."""
     rows = s.numel() // n
-    _launch('softmax_rows', load().mud_softmax_rows, ptr(s), rows, n, n, stream_ptr())
+    _launch('softmax_rows', s.device, load().mud_softmax_rows, ptr(s), rows, n, n, STREAM)
     return s
 
 
 def mul(a: View, b: View, out: View = None):
     out = View.empty(a.B, a.H, a.W, a.C, a.device) if out is None else out
-    _launch('mul', load().mud_mul, a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.npix, a.C, stream_ptr())
+    _launch('mul', a.device, load().mud_mul, a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.npix, a.C, STREAM)
     return out
 
 
 def gate_mix(g: View, att: View, other: View, out: View):
-    _launch('gate_mix', load().mud_gate_mix, g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.B, g.H * g.W, g.C,
-            out.stats_ptr, out.stats.shape[1] if out.stats is not None else 0, stream_ptr())
+    _launch('gate_mix', g.device, load().mud_gate_mix, g.ptr, g.ld, att.ptr, att.ld, other.ptr, other.ld, out.ptr, out.ld, g.B, g.H * g.W, g.C,
+            out.stats_ptr, out.stats.shape[1] if out.stats is not None else 0, STREAM)
     return out
 
 
@@ -407,7 +418,7 @@ def resize_bilinear(x, size):
     Ho, Wo = int(size[0]), int(size[1])
     xin = _f32(x.float().contiguous())
     out = torch.empty(*x.shape[:-2], Ho, Wo, device=x.device, dtype=torch.float32)
-    _launch('resize_bilinear', load().mud_resize_bilinear, ptr(xin), xin.numel() // (H * W), H, W, Ho, Wo, ptr(out), stream_ptr())
+    _launch('resize_bilinear', x.device, load().mud_resize_bilinear, ptr(xin), xin.numel() // (H * W), H, W, Ho, Wo, ptr(out), STREAM)
     return out
 
 
@@ -416,7 +427,7 @@ def affine_clamp(x, scale, shift, lo, hi):
     require_gpu(x)
     xin = _f32(x.float().contiguous())
     out = torch.empty_like(xin)
-    _launch('affine_clamp', load().mud_affine_clamp, ptr(xin), xin.numel(), float(scale), float(shift), float(lo), float(hi), ptr(out), stream_ptr())
+    _launch('affine_clamp', x.device, load().mud_affine_clamp, ptr(xin), xin.numel(), float(scale), float(shift), float(lo), float(hi), ptr(out), STREAM)
     return out
 
 

@@ -178,9 +178,11 @@ class GraphSampler:
 
     def _step(self):
         x01 = self.g1(self.x, self.c1, self.c2, self.c3, self.t, self.z)
-        x02 = self.g2(self.x, self.c1, self.c2, self.c3, self.t, self.z, x01)
+        p01 = x01 if x01.shape[1] == 1 else x01[:, :1].contiguous()      # x_0_1[:, [0], :] of the reference loop (engine/test.py:193-195)
+        x02 = self.g2(self.x, self.c1, self.c2, self.c3, self.t, self.z, p01)
+        p02 = x02 if x02.shape[1] == 1 else x02[:, :1].contiguous()
         self.x01, self.x02 = x01, x02
-        self.x_new = sample_posterior_combine(self.coef, x01, x02, self.x, self.t, self.noise)
+        self.x_new = sample_posterior_combine(self.coef, p01, p02, self.x, self.t, self.noise)
 
     def _capture(self, warmup):
         """Two graphs: the FIRST reverse step (fills the generators' loop caches: everything that depends on the condition
@@ -210,15 +212,19 @@ class GraphSampler:
             for g_ in gens:
                 g_.end_loop_cache()
 
-    def sample(self, cond1, cond2, cond3, x_init, n_time, zs=None, noises=None, return_steps=False):
+    def sample(self, cond1, cond2, cond3, x_init, n_time, zs=None, noises=None, return_steps=False, generator=None):
+        """zs / noises: injected per-step draws (both or neither).  Otherwise they are drawn on the device, from `generator`
+        (a torch.Generator on this device) when given, else from the device's global generator."""
+        if (zs is None) != (noises is None):
+            raise ValueError('GraphSampler.sample: pass zs and noises together (or neither)')
         self.c1.copy_(cond1); self.c2.copy_(cond2); self.c3.copy_(cond3)
         self.x.copy_(x_init)
         steps = []
         for k, i in enumerate(reversed(range(n_time))):
             self.t.fill_(i)
             if zs is None:
-                self.z.normal_()
-                self.noise.normal_()
+                self.z.normal_(generator=generator)
+                self.noise.normal_(generator=generator)
             else:
                 self.z.copy_(zs[k]); self.noise.copy_(noises[k])
             if k == 0:

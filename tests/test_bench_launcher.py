@@ -1,0 +1,92 @@
+"""bench.py as its own multi-rank launcher (SURVEY.md section 8 rows d/e; reference analogue engine/train.py:1454-1470):
+`python bench.py --gpus N` must start N ranks itself before any GPU call, wire RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*,
+relay rank 0's line with n_gpus == N, and fail when a rank fails.  Exercised on CPU over gloo with the stand-in timed
+region (MUDIFF_BENCH_DRYRUN=1); the real worker shares the rank plumbing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+BENCH = os.path.join(REPO, 'bench.py')
+
+
+def _run(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(MUDIFF_BENCH_DRYRUN='1', **env)
+    return subprocess.run([sys.executable, BENCH, *args], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def _line(p):
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, (p.stdout, p.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_n_gpus_2():
+    p = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p)
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == [0, 1] and d['scaling'] == 'weak'
+    assert d['ms_per_step'] >= 20.0          # MAX over ranks: rank 1's stand-in region is the longer one (2 x 10 ms)
+
+
+def test_strong_scaling_shards_cover_the_total_once():
+    p = _run(['--gpus', '3', '--total-slices', '37', '--batch', '4'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p)
+    assert d['n_gpus'] == 3 and d['scaling'] == 'strong'
+    assert d['shards'] == [[0, 13], [13, 25], [25, 37]]
+
+
+def test_a_failing_rank_fails_the_launcher_and_stops_the_others():
+    p = _run(['--gpus', '2'], MUDIFF_BENCH_FAIL_RANK='1')       # rank 0 would wait for rank 1 in the rendezvous forever
+    assert p.returncode != 0
+    assert 'rank 1 exited with code 3' in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_world_size_must_equal_gpus_under_an_external_launcher():
+    p = _run(['--gpus', '8'], WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)
+
+
+def test_single_rank_needs_no_launcher():
+    d = _line(_run(['--gpus', '1']))
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == [0]
+
+
+def test_sweep_prints_one_line_with_the_counts_that_fit():
+    p = _run(['--sweep', '1,2,4', '--total-slices', '24', '--batch', '4'], MUDIFF_BENCH_VISIBLE_GPUS='2')
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p)
+    assert sorted(d['slices_per_s_by_gpus']) == ['1', '2'] and d['skipped_gpu_counts'] == [4] and d['scaling'] == 'strong'
+    assert d['ranks_seen_by_gpus'] == {'1': [0], '2': [0, 1]} and d['total_slices'] == 24
+
+
+def test_launcher_helpers():
+    sys.path.insert(0, REPO)
+    import bench
+    assert bench.last_json_line('noise\n{"a": 1}\ntrailing') == {'a': 1}
+    assert bench.last_json_line('nothing here') is None
+    assert len(bench.csrc_digest()) == 16
+    a = bench.parse(['--gpus', '4', '--total-slices', '512'])
+    assert a.gpus == 4 and a.total_slices == 512 and a.batch == 16
+
+
+@pytest.mark.parametrize('which', ['g1', 'g2'])
+def test_seeded_state_dict_equals_the_fixture_weight_table(which):
+    """mudiff_hip.weights.seeded_state_dict (used by bench.py's parity leg) must reproduce the weights the fixtures were
+    made with (oracle.make_state_dict), tensor for tensor."""
+    import torch
+    from oracle import mudiff_oracle as O
+    from backbones.ncsnpp_generator_adagn_feat import NCSNpp, NCSNpp_adaptive
+    from mudiff_hip.weights import seeded_state_dict
+    cfg = O.default_config(image_size=32, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(16,), num_res_blocks=1, embedding_type='fourier')
+    m = (NCSNpp if which == 'g1' else NCSNpp_adaptive)(cfg)
+    ours, ref = seeded_state_dict(m, which, 1234, cfg.fourier_scale), O.make_state_dict(cfg, which, 1234)
+    assert list(ours) == list(ref)
+    assert all(torch.equal(ours[k], ref[k]) for k in ref)

@@ -374,6 +374,87 @@ def test_small_models_every_step_vs_reference(tag):
     assert worst <= 1e-3
 
 
+@pytest.mark.parametrize('tag', ['s32', 's16t8'])
+def test_reference_shaped_loop_under_autocast_vs_reference(tag):
+    """Drop-in under the reference's OWN calling convention (engine/test.py:180-199): plain per-step generator calls written
+    here exactly like the reference's loop - inside torch.autocast (the reference wraps the generators in
+    torch.cuda.amp.autocast(), fp16 on a GPU), `x_0_1[:, [0], :]` advanced-index copies as pseudo-target and posterior
+    inputs, `.detach()` - against the outputs of the reference's fp32 CPU run.  The modules must ignore the ambient
+    autocast: fp32 out, <= 1e-3 per step."""
+    ops, S, *_ = _imports()
+    gd = load_golden('small_models.npz')
+    cfg = O.default_config(**SMALL_CFGS[tag])
+    generator1, generator2 = _build(cfg)
+    cond1, cond2, cond3 = (g(c) for c in small_conds(cfg))
+    x_init, zs, noises = sampler_inputs(cfg, 2)
+    coefficients = S.Posterior_Coefficients(cfg, DEV)
+    n_time = cfg.num_timesteps
+    x = g(x_init)
+    worst = 0.0
+    with torch.no_grad():
+        for k, i in enumerate(reversed(range(n_time))):
+            t = torch.full((x.size(0),), i, dtype=torch.int64).to(x.device)
+            latent_z = g(zs[k])
+            with torch.autocast('cuda', dtype=torch.float16):
+                x_0_1 = generator1(x, cond1, cond2, cond3, t, latent_z)
+                x_0_2 = generator2(x, cond1, cond2, cond3, t, latent_z, x_0_1[:, [0], :])
+                x_new = S.sample_posterior_combine(coefficients, x_0_1[:, [0], :], x_0_2[:, [0], :], x, t, noise=g(noises[k]))
+            assert x_0_1.dtype == x_0_2.dtype == x_new.dtype == torch.float32
+            for nm, v in zip(('x01', 'x02', 'xnew'), (x_0_1, x_0_2, x_new)):
+                worst = max(worst, maxdiff(v, gd[f'{tag}.step{k}.{nm}']))
+            x = x_new.detach()
+    print(f'{tag} reference-shaped loop under fp16 autocast: worst per-step max-abs vs reference = {worst:.2e}')
+    assert worst <= 1e-3
+
+
+def test_graph_sampler_two_channel_images_use_channel_zero():
+    """num_channels > 1: the reference loop feeds x_0_1[:, [0], :] to G2 and to the posterior (engine/test.py:193-195), which only
+    type-checks for 1-channel x_t; GraphSampler must slice the same way instead of passing the whole tensor (G2 then rejects the
+    2-channel pseudo-target exactly like the reference's conv would).  Checked on G1 alone through the eager loop's contract:
+    a 2-channel G1 output sliced to channel 0 equals the oracle's."""
+    ops, S, *_ = _imports()
+    from helpers import VARIANT_BASE, VARIANTS
+    cfg = O.default_config(**{**VARIANT_BASE, **VARIANTS['two_channels']})
+    g1, _ = _build(cfg)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 2, 32, 32, generator=gen)
+    cs = [torch.tanh(torch.randn(2, 2, 32, 32, generator=gen)) for _ in range(3)]
+    z = torch.randn(2, cfg.nz, generator=gen)
+    t = torch.full((2,), 1, dtype=torch.int64)
+    out = g1(g(x), *(g(c) for c in cs), g(t), g(z))
+    ref = O.g1_forward(O.make_state_dict(cfg, 'g1', 1234), cfg, x, *cs, t, z)
+    assert out.shape == (2, 2, 32, 32) and maxdiff(out[:, [0], :], ref[:, [0], :]) <= 1e-3
+
+
+def test_sampler_rejects_half_injected_draws():
+    ops, S, *_ = _imports()
+    cfg = O.default_config(**SMALL_CFGS['s32na'])
+    g1, g2 = _build(cfg)
+    smp = S.GraphSampler(S.Posterior_Coefficients(cfg, DEV), g1, g2, cfg, 1, 32, 32, DEV)
+    c = torch.zeros(1, 1, 32, 32, device=DEV)
+    with pytest.raises(ValueError):
+        smp.sample(c, c, c, c, cfg.num_timesteps, zs=[torch.zeros(1, cfg.nz, device=DEV)] * cfg.num_timesteps)
+
+
+def test_operands_on_different_gpus_are_rejected_and_foreign_device_launches_are_guarded():
+    """A launch goes to the device its operands live on, whatever the process's current device is; operands on two GPUs
+    are refused (the kernels take raw pointers).  With one visible GPU only the refusal of a CPU operand and the
+    same-device path can be exercised; with two, the cross-device cases run as well."""
+    import mudiff_hip
+    ops, S, *_ = _imports()
+    with pytest.raises(mudiff_hip.MudiffHipError):
+        ops.pixel_norm(torch.zeros(2, 8))
+    if torch.cuda.device_count() < 2:
+        return
+    a, b = torch.randn(4, 16, device='cuda:0'), torch.randn(4, 16, device='cuda:1')
+    with pytest.raises(mudiff_hip.MudiffHipError):
+        mudiff_hip.require_gpu(a, b)
+    with torch.cuda.device(0):                      # current device 0, operands on device 1
+        out = ops.pixel_norm(b)
+    ref = b.cpu() * torch.rsqrt((b.cpu() ** 2).mean(1, keepdim=True) + 1e-8)
+    assert out.device == b.device and maxdiff(out, ref) <= 1e-6
+
+
 def test_config2_full_size_every_step_vs_reference():
     """BASELINE config 2: 256x256, nf=64, ch_mult 1-2-4, 4 steps, dual generator, injected noise."""
     ops, S, *_ = _imports()
