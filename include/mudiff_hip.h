@@ -114,6 +114,18 @@ typedef struct mud_conv_args {
   int emul_cout;                                 /* `emul` applies to output channels < emul_cout only */
                                                  /* (0 = all): lets two convs that share their input   */
                                                  /* but differ in this epilogue run as one launch       */
+  /* mud_conv2d_mfma only - GroupNorm finalisation folded into the prologue (pro_mode AFFINE / AFFINE_SILU): when gn_sums  */
+  /* is set, pro_scale / pro_shift are ignored and every workgroup forms scale = gamma*rstd, shift = beta - mean*scale of   */
+  /* its sample from the producer-accumulated per-channel (sum, sumsq) itself - the arithmetic of                           */
+  /* mud_gn_scale_shift_from_sums, without its launch (layerspp.py:37-54 AdaptiveGroupNorm, :56-65 GroupNorm_Conv).         */
+  const double* gn_sums; int gn_sums_ld;         /* gn_sums[(b*gn_sums_ld + c)*2 + {0,1}], c < Cin                           */
+  int gn_G; float gn_eps; double gn_count;       /* groups (Cin % gn_G == 0), eps, pixels per channel                        */
+  const float* gn_gamma; const float* gn_beta;   /* [Cin] (gn_bstride 0) or [B, .] rows gn_bstride floats apart, or NULL      */
+  int64_t gn_bstride;
+  /* mud_conv2d_mfma, ks 3 only - optional split-K workspace: when a launch would fill less than the chip (one slice at a   */
+  /* time), the K chunks of a tile are dealt to several workgroups that write raw partial tiles here, and a second small     */
+  /* launch adds them in a fixed order and applies the epilogue.  mud_conv2d_mfma_splitk_bytes() sizes it; NULL = never split. */
+  void* splitk_ws; int64_t splitk_ws_bytes;
 } mud_conv_args;
 
 /* Exact fp32 direct convolution (FMA chain per output), any ks/stride/pad/Cin/Cout.
@@ -132,6 +144,8 @@ int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout);
 int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride,
                      int ks, int Cin, int Cout, int nbatch, void* dst, void* stream);
 int mud_conv2d_mfma(const mud_conv_args* a, void* stream);
+/* Bytes of split-K workspace mud_conv2d_mfma would use for this call (0: the launch is not split). */
+int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* a);
 
 /* ---- FIR resampling (utils/op/upfirdn2d.cpp:20-31 + upfirdn2d_kernel.cu:109-209; python front
  *      ends backbones/up_or_down_sampling.py:149-262).

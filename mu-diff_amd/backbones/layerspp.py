@@ -96,7 +96,7 @@ class AdaptiveGroupNorm(nn.Module):
 
     def scale_shift(self, x: View, style_out):
         c = self.in_channel
-        return ops.gn_scale_shift(x, self.num_groups, style_out[:, :c], style_out[:, c:])
+        return ops.gn_lazy(x, self.num_groups, style_out[:, :c], style_out[:, c:])
 
     def forward(self, input, style):
         xv = View.from_nchw(input)
@@ -114,7 +114,7 @@ class GroupNorm_Conv(nn.Module):
         self.num_groups = num_groups
 
     def scale_shift(self, x: View):
-        return ops.gn_scale_shift(x, self.num_groups)
+        return ops.gn_lazy(x, self.num_groups)
 
     def forward(self, input):
         xv = View.from_nchw(input)
@@ -145,7 +145,8 @@ class AttnBlockpp(nn.Module, _Prepared):
     def run(self, x: View, out: View = None):
         p = self.prepared()
         c, n = self.channels, x.H * x.W
-        sc, sh = ops.gn_scale_shift(x, self.GroupNorm_0.num_groups, p['gamma'], p['beta'])
+        gn = ops.gn_lazy(x, self.GroupNorm_0.num_groups, p['gamma'], p['beta'])
+        sc, sh = (gn, None) if isinstance(gn, ops.LazyGN) else gn
         qkv = ops.conv(x, p['wqkv'], 1, 3 * c, mfma=True, pro=(sc, sh, PRO_AFFINE), bias=p['bqkv'])     # [B,H,W,3C]
         if ops.attention_supported(c):      # fused flash-style kernel: the N x N score matrix is never materialised
             h = ops.attention(qkv, c, float(int(c) ** (-0.5)))
@@ -275,7 +276,8 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         if self.dropout and self.training:
             raise NotImplementedError('dropout > 0 in training mode is not part of the inference path')
         p = self.prepared()
-        sc0, sh0 = self.GroupNorm_0.scale_shift(x, style0)
+        gn0 = self.GroupNorm_0.scale_shift(x, style0)
+        sc0, sh0 = (gn0, None) if isinstance(gn0, ops.LazyGN) else gn0
         if self.up:
             kk, up, down, pad = up_or_down_sampling.fir_params('up' if self.fir else 'naive_up', self.fir_kernel)
             h_in, _ = ops.fir_nhwc(x, kk, up, down, pad, pro=(sc0, sh0, PRO_AFFINE_SILU), want_h=True, want_x=False)
@@ -288,7 +290,8 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         else:
             x_skip = x
             h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena)
-        sc1, sh1 = self.GroupNorm_1.scale_shift(h, style1)
+        gn1 = self.GroupNorm_1.scale_shift(h, style1)
+        sc1, sh1 = (gn1, None) if isinstance(gn1, ops.LazyGN) else gn1
         if 'c2' in p and not self.up:
             x_skip = p['c2'](x_skip)
         return p['c1'](h, pro=(sc1, sh1, PRO_AFFINE_SILU), res=x_skip, out_scale=INV_SQRT2 if self.skip_rescale else 1.0, out=out)
@@ -318,7 +321,8 @@ class ConvFeatBlock(nn.Module, _Prepared):
     def run(self, x: View, out: View = None, arena=None):
         p = self.prepared()
         h = p['c1'](x, arena=arena)
-        sc, sh = self.group_norm.scale_shift(h)
+        gn = self.group_norm.scale_shift(h)
+        sc, sh = (gn, None) if isinstance(gn, ops.LazyGN) else gn
         return p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU), out=out)
 
     def forward(self, x):
@@ -351,7 +355,8 @@ class ConvBlock(nn.Module, _Prepared):
             h = p['c1'](x, arena=arena)
             if cache is not None and h.stats is not None:
                 cache.update(h=h, stats=h.stats.clone())
-        sc, sh = self.group_norm.scale_shift(h, style_out)
+        gn = self.group_norm.scale_shift(h, style_out)
+        sc, sh = (gn, None) if isinstance(gn, ops.LazyGN) else gn
         return p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU), out=out)
 
     def forward(self, x, style=None):
@@ -378,7 +383,8 @@ class ConvBlock_GAP(nn.Module, _Prepared):
     def run(self, x: View, arena=None):
         p = self.prepared()
         h = p['c1'](x, arena=arena)
-        sc, sh = self.group_norm.scale_shift(h)
+        gn = self.group_norm.scale_shift(h)
+        sc, sh = (gn, None) if isinstance(gn, ops.LazyGN) else gn
         h = p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU))
         gap = ops.channel_mean(h)
         assert gap.shape[1] == self.fc.in_features, f'GAP vector {gap.shape[1]} != fc.in_features {self.fc.in_features}'

@@ -31,10 +31,18 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef CM_STAGGER
+#define CM_STAGGER 0             // experiment knobs (scripts/build_variants.py); the shipped values are set here
+#endif
+#ifndef CM_PRIO
+#define CM_PRIO 0
+#endif
 #define CM_BN 64
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
 #define CM_PIX 80                // LDS bytes per pixel record of the A tile
+#define CM_GN_MAXC 1024         // channels of the folded GroupNorm finalisation (scale | shift arrays in LDS: 8 KiB)
+#define CM_GN_BYTES (2 * CM_GN_MAXC * 4)
 
 template <int KS, int MT, int WM, int WN>
 struct CmGeo {
@@ -58,14 +66,42 @@ struct CmGeo {
   static constexpr int PIECES = GB / 1024;              // 1 KiB DMA pieces per group
   static constexpr int A_BYTES = 2 * BUF;
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
+  static constexpr int GN_OFF = A_BYTES + 2 * GB;       // folded GroupNorm finalisation: scale | shift of the sample
   static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
-  static constexpr int LDS_BYTES = (A_BYTES + 2 * GB) > EP_BYTES ? (A_BYTES + 2 * GB) : EP_BYTES;
+  static constexpr int LDS_BYTES = (GN_OFF + CM_GN_BYTES) > EP_BYTES ? (GN_OFF + CM_GN_BYTES) : EP_BYTES;
   static_assert(NT % Q == 0, "staging split");
 };
 
 
 
 __device__ __forceinline__ bool mud_dev_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+
+// GroupNorm finalisation folded into the conv prologue (mud_conv_args.gn_*): scale / shift of sample b for all Cin channels
+// into LDS, same arithmetic and summation order as k_gn_from_sums (groupnorm.hip) - one thread per channel, the group's
+// (sum, sumsq) re-added by each of its channels (a few L1-resident fp64 pairs).
+__device__ __forceinline__ void cm_gn_to_lds(const mud_conv_args& a, int b, int tid, int nthreads, float* sc_lds) {
+  float* sh_lds = sc_lds + CM_GN_MAXC;
+  const int cpg = a.Cin / a.gn_G;
+  for (int c = tid; c < a.Cin; c += nthreads) {
+    const int g0 = (c / cpg) * cpg;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < cpg; ++i) {
+      const double* p = a.gn_sums + ((int64_t)b * a.gn_sums_ld + g0 + i) * 2;
+      s += p[0];
+      q += p[1];
+    }
+    const double n = a.gn_count * cpg, mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps)), meanf = (float)mean;
+    const float ga = a.gn_gamma ? a.gn_gamma[(int64_t)b * a.gn_bstride + c] : 1.0f;
+    const float be = a.gn_beta ? a.gn_beta[(int64_t)b * a.gn_bstride + c] : 0.0f;
+    const float sc = ga * rstd;
+    sc_lds[c] = sc;
+    sh_lds[c] = be - meanf * sc;
+  }
+}
 
 __device__ __forceinline__ float cm_fast_silu(float v) {
   // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): the result is rounded to bf16 hi+lo (2^-17) anyway
@@ -74,7 +110,7 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
 
 template <int KS, int MT, int WM, int WN, int PRO>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
-                                                                unsigned nblocks) {
+                                                                unsigned nblocks, int nsplit, int64_t split_stride) {
   using G = CmGeo<KS, MT, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -89,7 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   const int nt = lid % ntiles;                  // output-channel tile fastest: sharers of one A tile are neighbours
   const unsigned rest = lid / ntiles;
   const int tile = rest % tiles_per_img;
-  const int b = rest / tiles_per_img;
+  const unsigned rest2 = rest / tiles_per_img;
+  const int b = rest2 % (unsigned)a.B;
+  const int ksi = rest2 / (unsigned)a.B;        // split-K slice (small grids only: nsplit > 1, see cm_splits)
 
   const int64_t HW = (int64_t)a.H * a.W;
   int ty0 = 0, tx0 = 0;
@@ -105,7 +143,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   const char* wb = (const char*)a.w + (int64_t)b * a.w_bstride + (int64_t)nt * WN * tile_bytes;
   const float* psc = a.pro_scale + (int64_t)b * a.pro_ld;
   const float* psh = a.pro_shift + (int64_t)b * a.pro_ld;
-  const int nchunks = (k16s + G::CH - 1) / G::CH;
+  const int nchunks_all = (k16s + G::CH - 1) / G::CH;
+  const int per_split = (nchunks_all + nsplit - 1) / nsplit;
+  const int kc0 = ksi * per_split;                                           // this workgroup reduces chunks [kc0, nchunks)
+  const int nchunks = (kc0 + per_split < nchunks_all) ? kc0 + per_split : nchunks_all;
+  a.out += (int64_t)ksi * split_stride;                                      // its slab of raw partial sums (nsplit > 1)
 
   // ---- per-thread staging slots: pixel -> global element offset and LDS byte offset, fixed for all chunks.
   // Everything below is branch-free: padding pixels load a clamped (valid) address and are zeroed by a 0/1
@@ -136,15 +178,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
 
   f32x4 raw[G::NLOAD];
   f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
-  auto fetch_a = [&](int chunk) {
+  const bool gn_fold = (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) && a.gn_sums != nullptr;   // workgroup-uniform
+  const float* const gn_sc = (const float*)(smem + G::GN_OFF);
+  auto fetch_raw = [&](int chunk) {
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
+  };
+  auto fetch_ss = [&](int chunk) {
     if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
-      psc_r = *(const f32x4*)(psc + c);
-      psh_r = *(const f32x4*)(psh + c);
+      int c = chunk * G::KCH + q * 4;
+      c = c < a.Cin ? c : 0;
+      if (gn_fold) {
+        psc_r = *(const f32x4*)(gn_sc + c);
+        psh_r = *(const f32x4*)(gn_sc + CM_GN_MAXC + c);
+      } else {
+        psc_r = *(const f32x4*)(psc + c);
+        psh_r = *(const f32x4*)(psh + c);
+      }
     }
+  };
+  auto fetch_a = [&](int chunk) {
+    fetch_raw(chunk);
+    fetch_ss(chunk);
   };
   auto store_a_slots = [&](int chunk, char* buf, int j0, int j1) {
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
@@ -175,7 +232,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   // ---- B operand: groups of GS steps are copied global -> LDS by direct-to-LDS loads (no VGPRs, 1 KiB per
   // wave instruction, each wave moves a quarter of the group) into a 2-slot ring, one group ahead of its use.
   // The packed layout already is the LDS image (16-B halves pre-swizzled for conflict-free ds_read_b128).
-  const int total_groups = (k16s * G::TAPS + G::GS - 1) / G::GS;
+  const int total_groups_all = (k16s * G::TAPS + G::GS - 1) / G::GS;
+  const int total_groups = (nchunks * G::NG < total_groups_all) ? nchunks * G::NG : total_groups_all;   // nothing is fetched past this slice
   char* const bring = smem + G::B_OFF;
   auto dma_b = [&](int gg) {                    // group gg -> ring slot gg & 1
     if (gg >= total_groups) return;             // wave-uniform
@@ -202,9 +260,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
   // ---- prologue: chunk 0 into A buffer 0, B group 0 into ring slot 0
-  dma_b(0);
-  fetch_a(0);
-  store_a(0, smem);
+  dma_b(kc0 * G::NG);
+  fetch_raw(kc0);
+  if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
+    cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF));
+    __syncthreads();
+  }
+  fetch_ss(kc0);
+  store_a(kc0, smem + (kc0 & 1) * G::BUF);
   __syncthreads();
 
   // ---- residual prefetch: the epilogue adds a [pixels x channels] tile of `res` the size of the accumulators.  Loaded
@@ -217,7 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
   const bool pre_res = KS == 3 && WM * WN >= 8 && a.res && vec && !a.sub2;      // (the 4-wave variants have no registers to spare)
   f32x4 rpre[2][MT][4];
-  const int kc_pre = nchunks > 3 ? nchunks - 3 : 0;
+  const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
   auto prefetch_res = [&]() {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -229,13 +292,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
           const int gy = ty0 + wm * MT + m, gx = tx0 + pass * 8 + (lane >> 3);
           const bool ok = gy < a.H && gx < a.W && co4 < a.Cout;
           const int64_t opix = ((int64_t)b * a.H + (ok ? gy : 0)) * a.W + (ok ? gx : 0);
-          const f32x4 v = *(const f32x4*)(a.res + opix * a.ldr + (ok ? co4 : 0));
-          rpre[n][m][pass] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+          // no select on the loaded value here: it would make the wave wait for the load in the middle of the K loop (the
+          // compiler placed 16 loads + 16 waits back to back); out-of-range lanes read a clamped address and the epilogue
+          // never uses their value
+          rpre[n][m][pass] = *(const f32x4*)(a.res + opix * a.ldr + (ok ? co4 : 0));
         }
     }
   };
 
-  for (int kc = 0; kc < nchunks; ++kc) {
+#if CM_STAGGER || CM_PRIO == 1
+  const bool late_half = WM * WN == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;   // waves 4-7 (wave-uniform, scalar)
+#endif
+#if CM_PRIO == 1
+  if (late_half) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every arbitration by age: static priority instead
+#endif
+  for (int kc = kc0; kc < nchunks; ++kc) {
     char* cur = smem + (kc & 1) * G::BUF;
     char* nxt = smem + ((kc + 1) & 1) * G::BUF;
     const bool more = kc + 1 < nchunks;
@@ -246,6 +317,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       dma_b(gg + 1);                            // next group's weights stream in under this group's MFMAs
       if (g == 0 && more) fetch_a(kc + 1);
       const char* bcur = bring + (gg & 1) * G::GB + wn * G::GB1;
+#if CM_STAGGER
+      // role stagger (8-wave workgroups): the two waves of a SIMD run the same program between the same barriers; left alone
+      // they reach their staging VALU work and their MFMA clusters together.  The second-dispatched half (waves 4-7) converts
+      // its share of chunk k+1 BEFORE the group's MFMAs, the first half AFTER them, so one partner's VALU runs beside the
+      // other's matrix work (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+      constexpr bool kStagger = (WM * WN == 8) && G::NG == 3;
+      const int gj0 = (g == 1) ? 0 : G::NLOAD / 2, gj1 = (g == 1) ? G::NLOAD / 2 : G::NLOAD;
+      if (kStagger && more && g >= 1 && late_half) store_a_slots(kc + 1, nxt, gj0, gj1);
+#else
+      constexpr bool kStagger = false;
+#endif
+#if CM_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int sg = 0; sg < G::GS; ++sg) {
         const int st = g * G::GS + sg;          // step inside the chunk: KS=3: tap; KS=1: k16 half
@@ -275,12 +360,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
         }
         // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),
         // so the conversion VALU work interleaves with matrix work instead of forming one long MFMA-free stretch
-        if (more && G::NG > 1 && st >= G::GS) {
+        if (!kStagger && more && G::NG > 1 && st >= G::GS) {
           constexpr int SPAN = G::STEPS - G::GS;                   // steps available for staging
           const int j0 = ((st - G::GS) * G::NLOAD) / SPAN, j1 = ((st - G::GS + 1) * G::NLOAD) / SPAN;
           store_a_slots(kc + 1, nxt, j0, j1);
         }
       }
+#if CM_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#if CM_STAGGER
+      if (kStagger && more && g >= 1 && !late_half) store_a_slots(kc + 1, nxt, gj0, gj1);
+#endif
       if (G::NG == 1 && more) store_a(kc + 1, nxt);
       __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
     }
@@ -432,7 +523,8 @@ struct CmGeoRegB {
   static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
   static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
   static constexpr int BUF = CH * PLANE;                // [k16 s]
-  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int GN_OFF = 2 * BUF;                // folded GroupNorm finalisation: scale | shift of the sample
+  static constexpr int LDS_BYTES = GN_OFF + CM_GN_BYTES;
   static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
   static constexpr int ITEMS = P * Q;
   static constexpr int NLOAD = (ITEMS + 255) / 256;
@@ -501,15 +593,30 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
 
   f32x4 raw[G::NLOAD];
   f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
-  auto fetch_a = [&](int chunk) {
+  const bool gn_fold = (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) && a.gn_sums != nullptr;   // workgroup-uniform
+  const float* const gn_sc = (const float*)(smem + G::GN_OFF);
+  auto fetch_raw = [&](int chunk) {
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
+  };
+  auto fetch_ss = [&](int chunk) {
     if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
-      psc_r = *(const f32x4*)(psc + c);
-      psh_r = *(const f32x4*)(psh + c);
+      int c = chunk * G::KCH + q * 4;
+      c = c < a.Cin ? c : 0;
+      if (gn_fold) {
+        psc_r = *(const f32x4*)(gn_sc + c);
+        psh_r = *(const f32x4*)(gn_sc + CM_GN_MAXC + c);
+      } else {
+        psc_r = *(const f32x4*)(psc + c);
+        psh_r = *(const f32x4*)(psh + c);
+      }
     }
+  };
+  auto fetch_a = [&](int chunk) {
+    fetch_raw(chunk);
+    fetch_ss(chunk);
   };
   auto store_a = [&](int chunk, char* buf) {
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
@@ -558,9 +665,14 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
   // ---- prologue: chunk 0 into buffer 0, first B fragments
-  fetch_a(0);
+  fetch_raw(0);
 #pragma unroll
   for (int s = 0; s < G::RING - 1; ++s) fetch_b(s, s);
+  if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
+    cm_gn_to_lds(a, b, tid, 256, (float*)(smem + G::GN_OFF));
+    __syncthreads();
+  }
+  fetch_ss(0);
   store_a(0, smem);
   __syncthreads();
 
@@ -784,6 +896,85 @@ extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, i
   return MUD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-K for small grids (one slice at a time: 64x64 maps give 128 workgroups of 16-32 serial K chunks on 256 CUs):
+// the K chunks are dealt to nsplit workgroups per output tile, each writes its raw fp32 partial tile to a slab, and this
+// kernel adds the slabs in a FIXED order and applies the conv epilogue (bias, time-embedding bias, residual, scale,
+// activation, GroupNorm statistics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_splitk_epilogue(mud_conv_args a, const float* __restrict__ part, int nsplit, int64_t split_stride,
+                                                         int ldp, int64_t npix, int pix_per_block) {
+  __shared__ float red[256 * 8];
+  const int quads = a.Cout >> 2;                       // float4 columns (host: Cout % 4 == 0, quads <= 256)
+  const int rows = 256 / quads;                        // pixels per pass
+  const int tq = threadIdx.x % quads, tr = threadIdx.x / quads;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int b = (int)(p0 / HW);                        // host: pix_per_block divides H*W -> one sample per block
+  const int co = tq * 4;
+  f32x4 badd = {0.f, 0.f, 0.f, 0.f};
+  if (tr < rows) {
+    if (a.bias) badd = *(const f32x4*)(a.bias + co);
+    if (a.bias2) badd += *(const f32x4*)(a.bias2 + (int64_t)b * a.bias2_ld + co);
+  }
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+  if (tr < rows) {
+    for (int64_t p = p0 + tr; p < p0 + pix_per_block && p < npix; p += rows) {
+      f32x4 v = *(const f32x4*)(part + p * ldp + co);
+      for (int k = 1; k < nsplit; ++k) v += *(const f32x4*)(part + k * split_stride + p * ldp + co);
+      v += badd;
+      if (a.res) v += *(const f32x4*)(a.res + p * a.ldr + co);
+      v *= a.out_scale;
+      if (a.act != MUD_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
+      }
+      *(f32x4*)(a.out + p * a.ldo + co) = v;
+      s4 += v;
+      q4 += v * v;
+    }
+  }
+  if (a.stats) {                                       // block-uniform
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[threadIdx.x * 8 + e] = s4[e];
+      red[threadIdx.x * 8 + 4 + e] = q4[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < quads * 8; i += 256) {   // one (quad, sum|sumsq component) at a time per thread
+      const int qd = i >> 3, e = i & 7;
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += red[(r * quads + qd) * 8 + e];
+      atomicAdd(a.stats + ((int64_t)b * a.stats_ld + qd * 4 + (e & 3)) * 2 + (e >> 2), (double)t);
+    }
+  }
+}
+
+// split-K needs a plain epilogue and whole, aligned float4 channel columns (the reduce kernel's access pattern)
+static bool cm_split_eligible(const mud_conv_args& a) {
+  return a.ks == 3 && !a.sub2 && !a.emul && !a.egate && a.Cout % 4 == 0 && a.Cout <= 1024 && a.ldo % 4 == 0 && (!a.res || a.ldr % 4 == 0) &&
+         mud_aligned16(a.out) && (!a.res || mud_aligned16(a.res)) && (!a.bias || mud_aligned16(a.bias)) &&
+         (!a.bias2 || (mud_aligned16(a.bias2) && a.bias2_ld % 4 == 0));
+}
+
+// how many K slices a 3x3 launch of `blocks` workgroups over `nchunks` 16-channel chunks is cut into (1 = no split)
+static int cm_splits(int64_t blocks, int nchunks) {
+  static const int force = getenv("MUD_CONV_SPLITK") ? atoi(getenv("MUD_CONV_SPLITK")) : -1;   // A/B knob: 0/1 = never, n = force n
+  int ns = 1;
+  if (force >= 0) ns = force < 1 ? 1 : force;
+  else if (blocks <= 192 && nchunks >= 16) {
+    // measured at one slice (profiles/r02_layer_times_b1_*.txt): 64x64 maps with >= 256 input channels gain (256->256: 50 -> 43 us,
+    // 512->256: 89 -> 59 us, 384->256: 70 -> 51 us); 128x128 / 256x256 maps and shorter reductions lose (every workgroup pays
+    // ~8 us of first-fetch + epilogue latency, and the second launch ~8 us), so they are left alone
+    ns = (int)((512 + blocks - 1) / blocks);
+    if (ns > 4) ns = 4;
+  }
+  if (ns > nchunks / 4) ns = nchunks / 4;             // at least 4 chunks per slice: the prologue / epilogue must stay amortised
+  if (ns < 1) ns = 1;
+  while (ns > 1 && (nchunks + ns - 1) / ns * (ns - 1) >= nchunks) --ns;   // every slice gets at least one chunk
+  return ns;
+}
+
 template <int KS, int MT, int WM, int WN, int PRO>
 static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   using G = typename std::conditional<KS == 3, CmGeo<KS, MT, WM, WN>, CmGeoRegB<KS, MT>>::type;
@@ -807,12 +998,37 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   } else {
     tiles = mud_cdiv((int64_t)a.H * a.W, G::P);
   }
-  const int64_t nblocks = tiles * ntiles * a.B;
+  int64_t nblocks = tiles * ntiles * a.B;
   MUD_REQUIRE(nblocks <= 0x7fffffff, "mud_conv2d_mfma: grid too large");
-  if constexpr (KS == 3)
+  if constexpr (KS == 3) {
+    // split-K (small grids): needs the caller's slab workspace, a plain epilogue and whole float4 channel columns
+    const int64_t npix = (int64_t)a.B * a.H * a.W;
+    int ns = 1;
+    if (a.splitk_ws && mud_aligned16(a.splitk_ws) && cm_split_eligible(a)) ns = cm_splits(nblocks, k16s);
+    if (ns > 1 && a.splitk_ws_bytes < (int64_t)ns * npix * a.Cout * 4) ns = 1;      // workspace too small: run unsplit
+    if (ns > 1) {
+      mud_conv_args p = a;                       // raw partial sums: no epilogue terms, output = slab ksi of the workspace
+      p.out = (float*)a.splitk_ws;
+      p.ldo = a.Cout;
+      p.bias = p.bias2 = p.res = nullptr;
+      p.out_scale = 1.0f;
+      p.act = MUD_ACT_NONE;
+      p.stats = nullptr;
+      const int64_t stride = npix * a.Cout;
+      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), G::LDS_BYTES, s, p, tiles_x,
+                         (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, stride);
+      MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K)");
+      const int64_t HW = (int64_t)a.H * a.W;
+      int ppb = 32;                              // pixels per block of the reduce: a divisor of H*W (one sample per block)
+      while (ppb > 1 && HW % ppb) ppb >>= 1;
+      hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)mud_cdiv(npix, ppb)), dim3(256), 0, s, a, (const float*)a.splitk_ws, ns, stride, a.Cout,
+                         npix, ppb);
+      MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K epilogue)");
+      return MUD_OK;
+    }
     hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO>), dim3((unsigned)nblocks), dim3(64 * WM * WN), G::LDS_BYTES, s, a, tiles_x, (int)tiles,
-                       ntiles, k16s, (unsigned)nblocks);
-  else
+                       ntiles, k16s, (unsigned)nblocks, 1, (int64_t)0);
+  } else
     hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
                        (unsigned)nblocks);
   MUD_CHECK_LAUNCH("mud_conv2d_mfma");
@@ -827,6 +1043,39 @@ static int cm_launch(const mud_conv_args& a, hipStream_t s) {
     case MUD_PRO_LRELU: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_LRELU>(a, s);
     default: return cm_launch_pro<KS, MT, WM, WN, MUD_PRO_AFFINE_SILU>(a, s);
   }
+}
+
+// 3x3 tile variant by problem size: big tiles (more MFMA work per weight byte) once they still fill the 256 CUs.
+// Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
+// beats MT=4 (one workgroup per CU) by 15-40 % on every layer shape; MT=1 only when MT=2 cannot give 2 blocks/CU.
+enum { CMV_8X2, CMV_16X1, CMV_MT2, CMV_MT1 };
+static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
+  const int64_t ntiles = mud_cdiv(a.Cout, CM_BN);
+  int64_t nb;
+  int v;
+  // 8-wave variant (8 rows x 32 px x 128 channels per workgroup, 4 x 2 waves): the staged input tile (GroupNorm +
+  // SiLU + split, the main non-MFMA cost) is shared by twice as many MFMAs; used when the layer has an even number
+  // of 64-channel tiles and still fills the chip
+  const int64_t blocks8 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * (ntiles / 2) * a.B;
+  // other layers (64 or an odd number of 64-channel tiles): 8 waves stacked along the rows (16 x 32 px x 64 channels):
+  // less halo per staged pixel and the weight ring is shared by twice as many waves (+4-7 % measured)
+  const int64_t blocks16 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 16) * ntiles * a.B;
+  const int64_t blocks2 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * ntiles * a.B;
+  static const bool no16 = getenv("MUD_CONV_NO16") != nullptr;   // A/B knob
+  if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
+  else if (!no16 && a.H >= 16 && blocks16 >= 256) v = CMV_16X1, nb = blocks16;
+  else if (blocks2 >= 512 && a.H >= 8) v = CMV_MT2, nb = blocks2;
+  else v = CMV_MT1, nb = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 4) * ntiles * a.B;
+  if (blocks) *blocks = nb;
+  return v;
+}
+
+extern "C" int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* ap) {
+  if (!ap || ap->ks != 3 || ap->B <= 0 || ap->H <= 0 || ap->W <= 0 || ap->Cin <= 0 || ap->Cout <= 0 || !cm_split_eligible(*ap)) return 0;
+  int64_t blocks = 0;
+  cm_variant3(*ap, &blocks);
+  const int ns = cm_splits(blocks, (int)mud_cdiv(ap->Cin, 16));
+  return ns > 1 ? (int64_t)ns * ap->B * ap->H * ap->W * ap->Cout * 4 : 0;
 }
 
 extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
@@ -844,12 +1093,20 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   MUD_REQUIRE(a.emul_cout >= 0 && a.emul_cout <= a.Cout, "mud_conv2d_mfma: emul_cout out of range");
   MUD_REQUIRE((!a.emul || a.ld_emul >= (a.emul_cout > 0 ? a.emul_cout : a.Cout)) && (!a.egate || (a.eother && a.ld_egate >= a.Cout && a.ld_eother >= a.Cout)), "mud_conv2d_mfma: bad emul / egate / eother view");
   MUD_REQUIRE(a.pro_mode >= MUD_PRO_NONE && a.pro_mode <= MUD_PRO_LRELU, "mud_conv2d_mfma: unknown prologue mode %d", a.pro_mode);
-  if (a.pro_mode == MUD_PRO_AFFINE || a.pro_mode == MUD_PRO_AFFINE_SILU) {
+  if ((a.pro_mode == MUD_PRO_AFFINE || a.pro_mode == MUD_PRO_AFFINE_SILU) && a.gn_sums) {
+    MUD_REQUIRE(a.Cin <= CM_GN_MAXC && a.gn_G > 0 && a.Cin % a.gn_G == 0 && a.gn_sums_ld >= a.Cin && a.gn_count > 0,
+                "mud_conv2d_mfma: folded GroupNorm needs Cin <= %d, Cin %% gn_G == 0, gn_sums_ld >= Cin, gn_count > 0 (Cin=%d gn_G=%d)", CM_GN_MAXC, a.Cin, a.gn_G);
+    MUD_REQUIRE((a.gn_gamma == nullptr) == (a.gn_beta == nullptr) && a.gn_bstride >= 0, "mud_conv2d_mfma: folded GroupNorm: gamma and beta come together");
+    a.pro_scale = a.pro_shift = a.x;   // never dereferenced
+    a.pro_ld = 0;
+  } else if (a.pro_mode == MUD_PRO_AFFINE || a.pro_mode == MUD_PRO_AFFINE_SILU) {
+    a.gn_sums = nullptr;
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),
                 "mud_conv2d_mfma: prologue arrays missing or misaligned");
   } else {
     a.pro_scale = a.pro_shift = a.x;   // never dereferenced
     a.pro_ld = 0;
+    a.gn_sums = nullptr;
   }
   if (a.B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -858,24 +1115,15 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   static const int force_mt = getenv("MUD_CONV_MT") ? atoi(getenv("MUD_CONV_MT")) : 0;   // tuning knob
   if (force_mt) {
     if (a.ks == 3) return (force_mt == 8 && ntiles % 2 == 0) ? cm_launch<3, 2, 4, 2>(a, s) : force_mt == 16 ? cm_launch<3, 2, 8, 1>(a, s) : force_mt == 1 ? cm_launch<3, 1>(a, s) : cm_launch<3, 2>(a, s);
-    return force_mt == 4 ? cm_launch<1, 4>(a, s) : force_mt == 2 ? cm_launch<1, 2>(a, s) : cm_launch<1, 1>(a, s);
+    return cm_launch<1, 1>(a, s);      // (256- and 512-pixel 1x1 tiles were measured 5-8 % slower and are no longer built)
   }
-  // Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
-  // beats MT=4 (one workgroup per CU) by 15-40 % on every layer shape; MT=1 only when MT=2 cannot give 2 blocks/CU.
   if (a.ks == 3) {
-    // 8-wave variant (8 rows x 32 px x 128 channels per workgroup, 4 x 2 waves): the staged input tile (GroupNorm +
-    // SiLU + split, the main non-MFMA cost) is shared by twice as many MFMAs; used when the layer has an even number
-    // of 64-channel tiles and still fills the chip
-    const int64_t blocks8 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * (ntiles / 2) * a.B;
-    if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) return cm_launch<3, 2, 4, 2>(a, s);
-    // other layers (64 or an odd number of 64-channel tiles): 8 waves stacked along the rows (16 x 32 px x 64 channels):
-    // less halo per staged pixel and the weight ring is shared by twice as many waves (+4-7 % measured)
-    const int64_t blocks16 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 16) * ntiles * a.B;
-    static const bool no16 = getenv("MUD_CONV_NO16") != nullptr;   // A/B knob
-    if (!no16 && a.H >= 16 && blocks16 >= 256) return cm_launch<3, 2, 8, 1>(a, s);
-    const int64_t blocks2 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * ntiles * a.B;
-    if (blocks2 >= 512 && a.H >= 8) return cm_launch<3, 2>(a, s);
-    return cm_launch<3, 1>(a, s);
+    switch (cm_variant3(a, nullptr)) {
+      case CMV_8X2: return cm_launch<3, 2, 4, 2>(a, s);
+      case CMV_16X1: return cm_launch<3, 2, 8, 1>(a, s);
+      case CMV_MT2: return cm_launch<3, 2>(a, s);
+      default: return cm_launch<3, 1>(a, s);
+    }
   }
   // 1x1 GEMMs: 128-pixel tiles (MT = 1) beat 256-pixel tiles (MT = 2) by 5-8 % on every skip-conv / NIN shape at batch 16
   // (scripts/bench_conv.py with MUD_CONV_MT=1/2) - these launches are HBM-bound and the smaller tile keeps more of them in flight

@@ -40,6 +40,9 @@ class ConvArgs(C.Structure):
         ('sub2', C.c_int),
         ('stats', C.c_void_p), ('stats_ld', C.c_int),
         ('emul_cout', C.c_int),
+        ('gn_sums', C.c_void_p), ('gn_sums_ld', C.c_int), ('gn_G', C.c_int), ('gn_eps', C.c_float), ('gn_count', C.c_double),
+        ('gn_gamma', C.c_void_p), ('gn_beta', C.c_void_p), ('gn_bstride', C.c_int64),
+        ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
     ]
 
 
@@ -60,6 +63,7 @@ _SIGNATURES = {
     'mud_packed_weight_bytes': (_L, [_I, _I, _I]),
     'mud_pack_weights': (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     'mud_conv2d_mfma': (_I, [C.POINTER(ConvArgs), _P]),
+    'mud_conv2d_mfma_splitk_bytes': (_L, [C.POINTER(ConvArgs)]),
     'mud_upfirdn2d': (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mud_fir_nhwc': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
     'mud_minibatch_stddev': (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),

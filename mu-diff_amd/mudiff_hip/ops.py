@@ -239,6 +239,54 @@ def gn_scale_shift(x: View, G, gamma=None, beta=None, eps=1e-6):
     return ss[0], ss[1]
 
 
+class LazyGN:
+    """GroupNorm scale / shift of a view whose producers already accumulated the per-channel (sum, sumsq): nothing is
+    launched for it.  A consumer that can finalise it in its own prologue (mud_conv2d_mfma: mud_conv_args.gn_*) takes it as
+    `pro=(lazy, None, mode)`; any other consumer calls `.tensors()` (one small launch, cached)."""
+    __slots__ = ('x', 'G', 'gamma', 'beta', 'bstride', 'eps', '_ss')
+
+    def __init__(self, x: View, G, gamma, beta, bstride, eps):
+        self.x, self.G, self.gamma, self.beta, self.bstride, self.eps, self._ss = x, G, gamma, beta, bstride, eps, None
+
+    def tensors(self):
+        if self._ss is None:
+            x = self.x
+            ss = torch.empty(2, x.B, x.C, device=x.device, dtype=torch.float32)
+            _launch('gn_from_sums', x.device, load().mud_gn_scale_shift_from_sums, x.stats_ptr, x.stats.shape[1], x.B, x.C, self.G,
+                    float(x.H * x.W), self.eps, ptr(self.gamma), ptr(self.beta), self.bstride, ptr(ss[0]), ptr(ss[1]), x.C, STREAM)
+            self._ss = (ss[0], ss[1])
+        return self._ss
+
+    def __iter__(self):          # `sc, sh = ...` keeps working for callers that need the arrays
+        return iter(self.tensors())
+
+
+def gn_lazy(x: View, G, gamma=None, beta=None, eps=1e-6):
+    """gn_scale_shift whose finalisation is deferred to the consumer when the producers left (sum, sumsq) behind
+    (-> LazyGN); otherwise the two-pass statistics run now (-> (scale, shift))."""
+    if x.stats is None or not FOLD_GN:
+        return gn_scale_shift(x, G, gamma, beta, eps)
+    bstride = 0
+    if gamma is not None:
+        assert gamma.stride(-1) == 1 and beta.stride(-1) == 1 and gamma.shape[-1] == x.C
+        if gamma.dim() == 2:
+            assert gamma.shape[0] == x.B and gamma.stride(0) == beta.stride(0)
+            bstride = gamma.stride(0)
+    return LazyGN(x, G, gamma, beta, bstride, eps)
+
+
+import os as _os
+FOLD_GN = _os.environ.get('MUD_FOLD_GN', '1') != '0'      # A/B knob: 0 = one gn_from_sums launch per GroupNorm (round-1 behaviour)
+
+
+def resolve_pro(pro):
+    """(scale, shift, mode) with the arrays materialised (for consumers that cannot fold the GroupNorm finalisation)."""
+    if pro is not None and isinstance(pro[0], LazyGN):
+        sc, sh = pro[0].tensors()
+        return (sc, sh, pro[2])
+    return pro
+
+
 def channel_mean(x: View):
     lib = load()
     HW = x.H * x.W
@@ -295,8 +343,17 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     a.x, a.B, a.H, a.W, a.Cin, a.ldx = x.ptr, x.B, x.H, x.W, x.C, x.ld
     a.w, a.w_bstride = ptr(w), w_bstride
     a.ks, a.stride, a.pad = ks, stride, pad
+    keep = None
+    if pro is not None and isinstance(pro[0], LazyGN) and not (mfma and x.C <= 1024 and pro[0].x.stats is not None):
+        pro = resolve_pro(pro)
     if pro is not None and pro[2] == PRO_LRELU:
         a.pro_mode = PRO_LRELU
+    elif pro is not None and isinstance(pro[0], LazyGN):      # finalised inside the kernel's prologue
+        gn = keep = pro[0]
+        assert gn.x.C == x.C and gn.x.B == x.B
+        a.pro_mode = pro[2]
+        a.gn_sums, a.gn_sums_ld, a.gn_G, a.gn_eps, a.gn_count = gn.x.stats_ptr, gn.x.stats.shape[1], gn.G, gn.eps, float(gn.x.H * gn.x.W)
+        a.gn_gamma, a.gn_beta, a.gn_bstride = ptr(gn.gamma), ptr(gn.beta), gn.bstride
     elif pro is not None:
         sc, sh, mode = pro
         assert sc.shape == (x.B, x.C) and sc.stride(1) == 1 and sh.stride() == sc.stride()
@@ -324,6 +381,11 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
     if out.stats is not None:
         a.stats, a.stats_ld = out.stats_ptr, out.stats.shape[1]
+    if mfma and ks == 3:          # small grids (one slice at a time): split-K slabs, stream-ordered scratch (graph-capture safe)
+        nws = lib.mud_conv2d_mfma_splitk_bytes(C.byref(a))
+        if nws > 0:
+            keep = (keep, torch.empty(nws, device=x.device, dtype=torch.uint8))
+            a.splitk_ws, a.splitk_ws_bytes = ptr(keep[1]), nws
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks     # algorithmic (sub2 issues 4x this)
@@ -360,7 +422,7 @@ def fir_nhwc(x: View, kernel2d, up, down, pad, pro=None, want_h=True, want_x=Fal
     sc = sh = None
     ld = mode = 0
     if pro is not None:
-        sc, sh, mode = pro
+        sc, sh, mode = resolve_pro(pro)
         ld = sc.stride(0)
     _launch('fir_nhwc', x.device, load().mud_fir_nhwc, x.ptr, x.B, x.H, x.W, x.C, x.ld, k.ctypes.data_as(C.POINTER(C.c_float)), kh, kw, up, down,
             pad[0], pad[1], ptr(sc), ptr(sh), ld, mode, oh.ptr if oh else None, oh.ld if oh else 0, ox.ptr if ox else None,

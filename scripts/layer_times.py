@@ -13,11 +13,11 @@ g1.load_state_dict(O.make_state_dict(cfg, 'g1', 1234)); g2.load_state_dict(O.mak
 x = torch.randn(B, 1, 256, 256, device=dev); c = [torch.randn(B, 1, 256, 256, device=dev) for _ in range(3)]
 t = torch.full((B,), 3, dtype=torch.int64, device=dev); z = torch.randn(B, cfg.nz, device=dev)
 orig = ops._launch
-def tagged(name, fn, *args, flops=0.0, nbytes=0.0):
+def tagged(name, dev_, fn, *args, flops=0.0, nbytes=0.0):
     if name.startswith('conv_'):
         a = args[0]._obj
         name = f'{name} {a.H:3d}^2 {a.Cin:4d}->{a.Cout:4d} pro{a.pro_mode} res{int(bool(a.res))} st{int(bool(a.stats))} ld{a.ldx}/{a.ldo}'
-    return orig(name, fn, *args, flops=flops, nbytes=nbytes)
+    return orig(name, dev_, fn, *args, flops=flops, nbytes=nbytes)
 ops._launch = tagged
 for it in range(2):
     ops.PROFILE.enable()

@@ -209,6 +209,94 @@ def test_epilogue_statistics_equal_two_pass_groupnorm(mfma, Cin, Cout, H, W):
     assert maxdiff(y * sc1.cpu()[:, :, None, None] + sh1.cpu()[:, :, None, None], ref) < 2e-5
 
 
+@pytest.mark.parametrize('B,H,W,C,Cout,ks,silu', [(2, 20, 37, 48, 96, 3, True), (3, 16, 16, 320, 64, 3, True), (1, 64, 64, 256, 256, 3, True),
+                                                    (2, 24, 24, 192, 128, 3, False), (2, 16, 16, 64, 192, 1, False), (1, 9, 7, 24, 16, 3, True)])
+def test_groupnorm_folded_into_conv_prologue(B, H, W, C, Cout, ks, silu):
+    """mud_conv_args.gn_*: the consumer conv finalises the GroupNorm of its input from the producer-accumulated sums in its own
+    prologue (no gn_from_sums launch).  Must equal the materialised scale / shift path on the same sums, and torch's
+    group_norm -> (silu) -> conv in fp64 (AdaptiveGroupNorm + conv, reference layerspp.py:37-54,293-318)."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(C + Cout + ks)
+    src = torch.randn(B, C, H, W, generator=gen) * 1.5 + 0.3
+    G = min(C // 4, 32)
+    arena = ops.StatsArena(torch.device(DEV))
+    wide = ops.View.empty(B, H, W, C + 8, DEV, arena)                  # the input is a channel slice of a concat buffer
+    x = wide.slice(4, C)
+    ops.fir_nhwc(ops.View.from_nchw(g(src)), [[1.0]], 1, 1, (0, 0))[0]       # (warm the FIR path; the sums come from a conv below)
+    eye = torch.zeros(C, C, 1, 1)
+    eye[torch.arange(C), torch.arange(C)] = 1.0
+    ops.conv(ops.View.from_nchw(g(src)), ops.pack_conv_weight(g(eye)), 1, C, mfma=True, out=x)      # producer: copies src, accumulates sums
+    xs = x.to_nchw().cpu()
+    gamma, beta = g(torch.randn(B, C, generator=gen)), g(torch.randn(B, C, generator=gen))
+    w = torch.randn(Cout, C, ks, ks, generator=gen) / math.sqrt(C * ks * ks)
+    bias = torch.randn(Cout, generator=gen)
+    wp = ops.pack_conv_weight(g(w))
+    mode = ops.PRO_AFFINE_SILU if silu else ops.PRO_AFFINE
+    lazy = ops.gn_lazy(x, G, gamma, beta)
+    assert isinstance(lazy, ops.LazyGN)
+    ops.PROFILE.enable()
+    out_fold = ops.conv(x, wp, ks, Cout, mfma=True, pro=(lazy, None, mode), bias=g(bias)).to_nchw().cpu()
+    names = {r[0] for r in ops.PROFILE.records}
+    ops.PROFILE.disable()
+    assert 'gn_from_sums' not in names                                 # nothing extra was launched
+    sc, sh = lazy.tensors()
+    out_mat = ops.conv(x, wp, ks, Cout, mfma=True, pro=(sc, sh, mode), bias=g(bias)).to_nchw().cpu()
+    assert maxdiff(out_fold, out_mat) <= 1e-6                          # same arithmetic, different place
+    h = gamma.cpu().double()[:, :, None, None] * F.group_norm(xs.double(), G, eps=1e-6) + beta.cpu().double()[:, :, None, None]
+    ref = F.conv2d(F.silu(h) if silu else h, w.double(), bias.double(), padding=ks // 2)
+    err = maxdiff(out_fold, ref)
+    print(f'folded GN + conv{ks}x{ks} {C}->{Cout}: max-abs vs fp64 {err:.2e}')
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 64, 64, 256, 256), (1, 64, 64, 512, 256), (1, 32, 32, 384, 128), (1, 40, 24, 320, 64), (4, 64, 64, 256, 256)])
+def test_conv_split_k_small_grids(B, H, W, Cin, Cout):
+    """Small grids (one slice at a time) deal the K chunks of a tile to several workgroups (raw partial slabs + a fixed-order
+    reduce that applies the epilogue).  Checked against fp64 with every epilogue term on (bias, time bias, residual, scale,
+    statistics), and against the unsplit kernel (no workspace passed -> never split)."""
+    import ctypes as C_
+    import mudiff_hip
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / math.sqrt(Cin * 9)
+    bias, b2 = torch.randn(Cout, generator=gen), torch.randn(B, Cout, generator=gen)
+    res = torch.randn(B, Cout, H, W, generator=gen)
+    sc, sh = torch.rand(B, Cin, generator=gen) + 0.5, torch.randn(B, Cin, generator=gen)
+    xv, rv, wp = ops.View.from_nchw(g(x)), ops.View.from_nchw(g(res)), ops.pack_conv_weight(g(w))
+    arena = ops.StatsArena(torch.device(DEV))
+    out = ops.View.empty(B, H, W, Cout, DEV, arena)
+    kw = dict(mfma=True, pro=(g(sc), g(sh), ops.PRO_AFFINE_SILU), bias=g(bias), bias2=g(b2), res=rv, out_scale=ops.INV_SQRT2)
+    ops.PROFILE.enable()
+    ops.conv(xv, wp, 3, Cout, out=out, **kw)
+    ops.PROFILE.disable()
+    y = out.to_nchw().cpu()
+    # was this launch split?  (the query the wrapper used)
+    a = mudiff_hip.ConvArgs()
+    a.x, a.B, a.H, a.W, a.Cin, a.ldx, a.ks, a.stride, a.pad = xv.ptr, B, H, W, Cin, Cin, 3, 1, 1
+    a.out, a.Cout, a.ldo, a.res, a.ldr = out.ptr, Cout, Cout, rv.ptr, Cout
+    nws = mudiff_hip.load().mud_conv2d_mfma_splitk_bytes(C_.byref(a))
+    print(f'split-K workspace for {B}x{H}x{W} {Cin}->{Cout}: {nws} bytes')
+    if B == 1:
+        assert nws > 0                                                  # every B=1 case of this table is a small grid with a long reduction
+    h = F.silu(x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None])
+    ref = (F.conv2d(h, w.double(), bias.double(), padding=1) + b2.double()[:, :, None, None] + res.double()) * ops.INV_SQRT2
+    err = maxdiff(y, ref)
+    print(f'  max-abs vs fp64 {err:.2e}')
+    assert err <= 1e-4
+    s_ref, q_ref = ref.sum(dim=(2, 3)), (ref * ref).sum(dim=(2, 3))
+    assert maxdiff(out.stats[..., 0], s_ref) <= 2e-6 * float(ref.abs().sum(dim=(2, 3)).max()) and maxdiff(out.stats[..., 1], q_ref) <= 2e-6 * float(q_ref.max())
+    if nws > 0:     # unsplit launch of the same problem through the raw C ABI (no workspace): same result to rounding
+        out2 = ops.View.empty(B, H, W, Cout, DEV)
+        a.w, a.pro_scale, a.pro_shift, a.pro_ld, a.pro_mode = C_.c_void_p(wp.data_ptr()), C_.c_void_p(g(sc).data_ptr()), C_.c_void_p(g(sh).data_ptr()), Cin, ops.PRO_AFFINE_SILU
+        scd, shd, bd, b2d = g(sc), g(sh), g(bias), g(b2)
+        a.pro_scale, a.pro_shift = C_.c_void_p(scd.data_ptr()), C_.c_void_p(shd.data_ptr())
+        a.bias, a.bias2, a.bias2_ld, a.out_scale, a.out = C_.c_void_p(bd.data_ptr()), C_.c_void_p(b2d.data_ptr()), Cout, ops.INV_SQRT2, out2.ptr
+        assert mudiff_hip.load().mud_conv2d_mfma(C_.byref(a), mudiff_hip.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert maxdiff(out2.to_nchw(), y) <= 2e-5
+
+
 def test_fir_against_reference_golden():
     ops, S, L, UD, *_ = _imports()
     from utils.op import upfirdn2d
