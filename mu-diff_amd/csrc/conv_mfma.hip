@@ -37,6 +37,9 @@
 #ifndef CM_PRIO
 #define CM_PRIO 0
 #endif
+#ifndef CM_FAKE16
+#define CM_FAKE16 0
+#endif
 #define CM_BN 64
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
@@ -352,9 +355,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
             const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
+#if CM_FAKE16
+              // TIMING PROBE ONLY (results are wrong): the same operand reads and the same MFMA cycles issued as two
+              // 16x16x32 instructions per 32x32x16 one, to see what the other bf16 MFMA shape is worth in THIS kernel
+              // before re-laying out the operands for it (MI355X_MICROARCH.md, DVFS give-back item 7)
+              f32x4 q[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) q[i] = f32x4{acc[m][n][4 * i], acc[m][n][4 * i + 1], acc[m][n][4 * i + 2], acc[m][n][4 * i + 3]};
+              q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], q[0], 0, 0, 0);
+              q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], q[1], 0, 0, 0);
+              q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], q[2], 0, 0, 0);
+              q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], q[3], 0, 0, 0);
+              q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], q[0], 0, 0, 0);
+              q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], q[2], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[m][n][i] = q[i >> 2][i & 3];
+#else
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc[m][n], 0, 0, 0);
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+#endif
             }
           }
         }

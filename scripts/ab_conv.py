@@ -32,7 +32,11 @@ tot = np.zeros(len(libs))
 for H, Cin, Cout, res, cnt in shapes:
     x = torch.randn(B, H, H, Cin, device=dev)
     w = torch.randn(Cout, Cin, 3, 3, device=dev) / math.sqrt(Cin * 9)
+    if os.environ.get('AB_ZERO') == '1':      # DVFS probe: same instruction stream, no switching energy in the operands
+        x.zero_(); w.zero_()
     sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev)
+    if os.environ.get('AB_ZERO') == '1':
+        sh.zero_()                                # silu(sc * 0 + 0) = 0: the A operand is all zeros too
     r = torch.randn(B, H, H, Cout, device=dev) if res else None
     out = torch.empty(B, H, H, Cout, device=dev)
     stats = torch.zeros(B, Cout, 2, device=dev, dtype=torch.float64)

@@ -7,7 +7,7 @@ CSRC = os.path.join(ROOT, 'mu-diff_amd', 'csrc')
 s = open(os.path.join(CSRC, 'conv_mfma.hip')).read()
 s = s.replace("template <int KS, int MT, int WM, int WN>\nstruct CmGeo {", '''__device__ unsigned long long g_stamps[64 * 64];
 extern "C" int mud_debug_read_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
-#define STAMP(i) do { if (tid == 0 && blockIdx.x < 64 && (i) < 64) g_stamps[blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) do { if (tid == 0 && blockIdx.x < 64 && (i) < 64) g_stamps[blockIdx.x * 64 + (i)] = ((i) == 58 || (i) == 59) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
 template <int KS, int MT, int WM, int WN>
 struct CmGeo {''', 1)
 k0, k1 = s.index("void k_conv_mfma(mud_conv_args a"), s.index("// Variant for ks == 1")
@@ -22,11 +22,11 @@ def sub(old, new):
 
 sub("  const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles",
     "  const int wm = wave % WM, wn = wave / WM;\n  STAMP(0);")
-sub("  store_a(0, smem);\n  __syncthreads();", "  store_a(0, smem);\n  __syncthreads();\n  STAMP(1);")
+sub("  store_a(kc0, smem + (kc0 & 1) * G::BUF);\n  __syncthreads();", "  store_a(kc0, smem + (kc0 & 1) * G::BUF);\n  __syncthreads();\n  STAMP(1); STAMP(58);")
 sub("    if (pre_res && kc == kc_pre) prefetch_res();", "    STAMP(2 + kc);\n    if (pre_res && kc == kc_pre) prefetch_res();")
 sub("      __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves",
     "      if (kc == 2) STAMP(40 + 2 * g);\n      __syncthreads();\n      if (kc == 2) STAMP(41 + 2 * g);")
-sub("  // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]", "  STAMP(60);\n  // ---- epilogue")
+sub("  // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]", "  STAMP(60); STAMP(59);\n  // ---- epilogue")
 sub("  if (a.stats) {\n    __syncthreads();\n    if (tid < 128 * WN) {", "  STAMP(61);\n  if (a.stats) {\n    __syncthreads();\n    if (tid < 128 * WN) {")
 b = b[:b.rstrip().rfind("}")] + "  STAMP(62);\n}\n\n"
 src = os.path.join(CSRC, '_conv_stamp_tmp.hip')

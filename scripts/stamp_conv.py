@@ -29,6 +29,8 @@ for H, Cin, Cout, res in [(256, 64, 64, True), (256, 64, 64, False), (128, 128, 
     epi = st[:, 61] - st[:, 60]
     tail = st[:, 62] - st[:, 61]
     chunk = (st[:, 2 + nch - 1] - st[:, 2]) / max(nch - 1, 1)
+    clk = (st[:, 60] - st[:, 1]) / np.maximum(st[:, 59] - st[:, 58], 1) * 100.0      # MHz: s_memtime ticks per 100 MHz realtime tick
+    print(f'   in-kernel clock over the K loop: median {np.median(clk):.0f} MHz (min {clk.min():.0f}, max {clk.max():.0f})')
     f = lambda a: f'{np.median(a):8.0f}'
     grp = [int(np.median(st[:, 40 + i] - (st[:, 2 + 2] if i == 0 else st[:, 39 + i]))) for i in range(6)]
     print('   chunk 2: [group MFMAs+staging, barrier wait] x3 =', grp)
