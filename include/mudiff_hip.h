@@ -126,6 +126,10 @@ typedef struct mud_conv_args {
   /* time), the K chunks of a tile are dealt to several workgroups that write raw partial tiles here, and a second small     */
   /* launch adds them in a fixed order and applies the epilogue.  mud_conv2d_mfma_splitk_bytes() sizes it; NULL = never split. */
   void* splitk_ws; int64_t splitk_ws_bytes;
+  /* mud_conv2d_mfma, ks 3, pro_mode AFFINE_SILU, plain epilogue - the residual block's 1x1 skip convolution of the RAW input     */
+  /* (layerspp.py:320-321, x = Conv_2(x)) produced by the same launch: skip_out[pixel, co] = sum_ci x[pixel, ci] * skip_w + bias. */
+  /* skip_w: mud_pack_weights(ks = 1) of the [Cout, Cin] matrix; x is then read from HBM once instead of twice.  Cin <= 512.      */
+  const void* skip_w; const float* skip_bias; float* skip_out; int skip_ldo;
 } mud_conv_args;
 
 /* Exact fp32 direct convolution (FMA chain per output), any ks/stride/pad/Cin/Cout.

@@ -276,6 +276,7 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         if self.dropout and self.training:
             raise NotImplementedError('dropout > 0 in training mode is not part of the inference path')
         p = self.prepared()
+        fused = False
         gn0 = self.GroupNorm_0.scale_shift(x, style0)
         sc0, sh0 = (gn0, None) if isinstance(gn0, ops.LazyGN) else gn0
         if self.up:
@@ -289,10 +290,15 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
             h = p['c0'](h_in, bias2=tbias, arena=arena)
         else:
             x_skip = x
-            h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena)
+            fused = 'c2' in p and p['c0'].mfma and p['c2'].mfma and ops.fused_skip_ok(x, self.out_ch, PRO_AFFINE_SILU)
+            if fused:       # Conv_0 and the 1x1 skip Conv_2 read the same x: one launch stages it once and writes both
+                x_skip = View.empty(x.B, x.H, x.W, self.out_ch, x.device)
+                h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena, skip=(p['c2'].w, p['c2'].bias, x_skip))
+            else:
+                h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena)
         gn1 = self.GroupNorm_1.scale_shift(h, style1)
         sc1, sh1 = (gn1, None) if isinstance(gn1, ops.LazyGN) else gn1
-        if 'c2' in p and not self.up:
+        if 'c2' in p and not self.up and not fused:
             x_skip = p['c2'](x_skip)
         return p['c1'](h, pro=(sc1, sh1, PRO_AFFINE_SILU), res=x_skip, out_scale=INV_SQRT2 if self.skip_rescale else 1.0, out=out)
 

@@ -47,7 +47,7 @@
 #define CM_GN_MAXC 1024         // channels of the folded GroupNorm finalisation (scale | shift arrays in LDS: 8 KiB)
 #define CM_GN_BYTES (2 * CM_GN_MAXC * 4)
 
-template <int KS, int MT, int WM, int WN>
+template <int KS, int MT, int WM, int WN, bool DUAL = false>
 struct CmGeo {
   static constexpr int NT = 64 * WM * WN;               // threads per workgroup
   static constexpr int TAPS = KS * KS;
@@ -71,7 +71,17 @@ struct CmGeo {
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
   static constexpr int GN_OFF = A_BYTES + 2 * GB;       // folded GroupNorm finalisation: scale | shift of the sample
   static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
-  static constexpr int LDS_BYTES = (GN_OFF + CM_GN_BYTES) > EP_BYTES ? (GN_OFF + CM_GN_BYTES) : EP_BYTES;
+  // DUAL (3x3 conv + the block's 1x1 skip conv of the RAW input from one staging pass, see k_conv_mfma): a second, single-
+  // buffered A image of the tile's centre pixels [hi 32 B | lo 32 B] (64-B records, 16-B units XOR-swizzled by the column)
+  // and one slot for the 1x1 weights of the current chunk.  The GroupNorm arrays shrink to 512 channels to make room.
+  static constexpr int GN_MAXC = DUAL ? 512 : CM_GN_MAXC;
+  static constexpr int A2_OFF = GN_OFF + 2 * GN_MAXC * 4;
+  static constexpr int A2_BYTES = DUAL ? ROWS * 32 * 64 : 0;
+  static constexpr int B2_OFF = A2_OFF + A2_BYTES;
+  static constexpr int B2_BYTES = DUAL ? WN * CM_BSTEP : 0;
+  static constexpr int MAIN_BYTES = B2_OFF + B2_BYTES;
+  static constexpr int LDS_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(NT % Q == 0, "staging split");
 };
 
@@ -83,8 +93,8 @@ __device__ __forceinline__ bool mud_dev_aligned16(const void* p) { return (((uin
 // GroupNorm finalisation folded into the conv prologue (mud_conv_args.gn_*): scale / shift of sample b for all Cin channels
 // into LDS, same arithmetic and summation order as k_gn_from_sums (groupnorm.hip) - one thread per channel, the group's
 // (sum, sumsq) re-added by each of its channels (a few L1-resident fp64 pairs).
-__device__ __forceinline__ void cm_gn_to_lds(const mud_conv_args& a, int b, int tid, int nthreads, float* sc_lds) {
-  float* sh_lds = sc_lds + CM_GN_MAXC;
+__device__ __forceinline__ void cm_gn_to_lds(const mud_conv_args& a, int b, int tid, int nthreads, float* sc_lds, int maxc) {
+  float* sh_lds = sc_lds + maxc;
   const int cpg = a.Cin / a.gn_G;
   for (int c = tid; c < a.Cin; c += nthreads) {
     const int g0 = (c / cpg) * cpg;
@@ -111,10 +121,13 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
-template <int KS, int MT, int WM, int WN, int PRO>
+// DUAL: the launch also produces the residual block's 1x1 skip convolution of the RAW input (reference layerspp.py:320-321,
+// `x = self.Conv_2(x)`) from the same staged tile - skip_out = skip_w * x + skip_bias - so that x is read from HBM once instead
+// of twice (the skip convs are pure HBM streams: 3.3-4.8 TB/s, 8 % of a forward) at the price of one more tap's MFMAs.
+template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
                                                                 unsigned nblocks, int nsplit, int64_t split_stride) {
-  using G = CmGeo<KS, MT, WM, WN>;
+  using G = CmGeo<KS, MT, WM, WN, DUAL>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles
@@ -157,6 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   // mask; slots past the tile wrap around and redo another thread's item (identical value, same address).
   const int q = tid % G::Q;                     // this thread's float4 (4 channels) inside a chunk
   int goff[G::NLOAD], loff[G::NLOAD];
+  int loff2[DUAL ? G::NLOAD : 1];               // DUAL: byte offset of the slot's hi half in the raw centre image, or -1 (halo pixel)
   unsigned vmask = 0;                           // bit j: slot j is a real (non-padding) pixel
 #pragma unroll
   for (int j = 0; j < G::NLOAD; ++j) {
@@ -169,6 +183,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       const int gy = ty0 + py - 1, gx = tx0 + px - 1;
       valid = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       g = ((int64_t)gy * a.W + gx) * a.ldx;
+      if (DUAL) {
+        const bool centre = py >= 1 && py <= G::ROWS && px >= 1 && px <= 32 && tid + j * G::NT < G::ITEMS;   // (wrapped slots redo an item: skip)
+        const int col = px - 1, sw = (col >> 2) & 3;
+        loff2[j] = centre ? ((py - 1) * 32 + col) * 64 + ((((q & 3) >> 1) ^ sw) << 4) + (q & 1) * 8 : -1;
+      }
     } else {
       const int64_t fp = flat0 + p;
       valid = fp < HW;
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       c = c < a.Cin ? c : 0;
       if (gn_fold) {
         psc_r = *(const f32x4*)(gn_sc + c);
-        psh_r = *(const f32x4*)(gn_sc + CM_GN_MAXC + c);
+        psh_r = *(const f32x4*)(gn_sc + G::GN_MAXC + c);
       } else {
         psc_r = *(const f32x4*)(psc + c);
         psh_r = *(const f32x4*)(psh + c);
@@ -228,6 +247,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
       *(bf16x4*)(buf + loff[j]) = hi;
       *(bf16x4*)(buf + loff[j] + 32) = lo;
+      if (DUAL) {                               // the RAW value of the tile's centre pixels: A operand of the 1x1 skip conv
+        if (loff2[j] >= 0) {
+          const f32x4 rv = raw[j] * (cvalid ? 1.0f : 0.0f);
+          const bf16x4 rhi = __builtin_convertvector(rv, bf16x4);
+          const bf16x4 rlo = __builtin_convertvector(rv - __builtin_convertvector(rhi, f32x4), bf16x4);
+          char* a2 = smem + G::A2_OFF;
+          *(bf16x4*)(a2 + loff2[j]) = rhi;
+          *(bf16x4*)(a2 + (loff2[j] ^ 32)) = rlo;         // unit u -> u ^ 2: the lo half sits two 16-B units away under the same swizzle
+        }
+      }
     }
   };
   auto store_a = [&](int chunk, char* buf) { store_a_slots(chunk, buf, 0, G::NLOAD); };
@@ -252,21 +281,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
     }
   };
   const int lane_b = r * 32 + ((hh ^ ((r >> 3) & 1)) << 4);   // this lane's 16 B inside a [32 co][32 B] fragment image
+  // DUAL: the 1x1 weights of one chunk ([WN tiles][hi|lo][64 co][16 ci], 4 KiB per tile) -> their single LDS slot
+  auto dma_b2 = [&](int chunk) {
+    if (DUAL) {
+      if (wave < 4 * WN && chunk < nchunks) {   // wave-uniform: one 1 KiB piece per wave
+        const int t64 = wave >> 2, within = wave & 3;
+        const char* src = (const char*)a.skip_w + ((int64_t)(nt * WN + t64) * k16s + chunk) * CM_BSTEP + within * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + G::B2_OFF + wave * 1024), 16, 0, 0);
+      }
+    }
+  };
 
   const int lane_a = ((KS == 3) ? (wm * MT * G::PW + r) : (wm * MT * 32 + r)) * CM_PIX + hh * 16;
   f32x16 acc[MT][2];
+  f32x16 acc2[DUAL ? MT : 1][2];                // DUAL: the 1x1 skip conv of the raw input
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        acc[m][n][i] = 0.f;
+        if (DUAL) acc2[m][n][i] = 0.f;
+      }
+  const int lane_a2 = ((wm * MT) * 32 + r) * 64 + ((hh ^ ((r >> 2) & 3)) << 4);   // DUAL: this lane's hi unit in the raw centre image (row m adds 32 * 64)
 
   // ---- prologue: chunk 0 into A buffer 0, B group 0 into ring slot 0
   dma_b(kc0 * G::NG);
+  dma_b2(kc0);
   fetch_raw(kc0);
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
-    cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF));
+    cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF), G::GN_MAXC);
     __syncthreads();
   }
   fetch_ss(kc0);
@@ -281,7 +327,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
-  const bool pre_res = KS == 3 && WM * WN >= 8 && a.res && vec && !a.sub2;      // (the 4-wave variants have no registers to spare)
+  const bool pre_res = !DUAL && KS == 3 && WM * WN >= 8 && a.res && vec && !a.sub2;      // (the 4-wave variants have no registers to spare; DUAL has no residual)
   f32x4 rpre[2][MT][4];
   const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
   auto prefetch_res = [&]() {
@@ -334,6 +380,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
 #if CM_PRIO == 2
       __builtin_amdgcn_s_setprio(1);
 #endif
+      if (DUAL && g == 0) {
+        // skip conv: centre tap on the RAW tile.  Read here, at the head of the chunk: the single-buffered raw image and
+        // weight slot are rewritten for chunk k+1 from group 1 on, i.e. behind this group's barrier.
+        const char* b2 = smem + G::B2_OFF + wn * CM_BSTEP;
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          bh[n] = *(const bf16x8*)(b2 + n * 1024 + lane_b);
+          bl[n] = *(const bf16x8*)(b2 + CM_BPLANE + n * 1024 + lane_b);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const char* a2 = smem + G::A2_OFF + lane_a2 + m * (32 * 64);
+          const bf16x8 ah = *(const bf16x8*)a2;
+          const bf16x8 al = *(const bf16x8*)((const char*)((uintptr_t)a2 ^ 32));
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc2[m][n], 0, 0, 0);
+            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc2[m][n], 0, 0, 0);
+            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc2[m][n], 0, 0, 0);
+          }
+        }
+      }
+      if (DUAL && g == 1 && more) dma_b2(kc + 1);
 #pragma unroll
       for (int sg = 0; sg < G::GS; ++sg) {
         const int st = g * G::GS + sg;          // step inside the chunk: KS=3: tap; KS=1: k16 half
@@ -514,6 +584,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       }
     }
   }
+  if (DUAL) {
+    // second output: skip_out = skip_w * x + skip_bias (no residual / activation / statistics), same LDS-transposed 16-B stores
+    // (host: Cout % 4 == 0, skip_ldo % 4 == 0, 16-byte aligned skip_out)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int co = (nt * WN + wn) * CM_BN + n * 32 + r;
+      const float badd = (a.skip_bias && co < a.Cout) ? a.skip_bias[co] : 0.f;
+      const int col = (lane & 7) * 4, co4 = (nt * WN + wn) * CM_BN + n * 32 + col;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) ep[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * EP_LD + r] = acc2[m][n][reg] + badd;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int prow = pass * 8 + (lane >> 3);
+          const int gy = ty0 + wm * MT + m, gx = tx0 + prow;
+          const f32x4 v = *(const f32x4*)(ep + prow * EP_LD + col);
+          if (gy < a.H && gx < a.W && co4 < a.Cout) *(f32x4*)(a.skip_out + (((int64_t)b * a.H + gy) * a.W + gx) * a.skip_ldo + co4) = v;
+        }
+      }
+    }
+  }
   if (a.stats) {
     __syncthreads();
     if (tid < 128 * WN) {
@@ -544,6 +636,7 @@ struct CmGeoRegB {
   static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
   static constexpr int BUF = CH * PLANE;                // [k16 s]
   static constexpr int GN_OFF = 2 * BUF;                // folded GroupNorm finalisation: scale | shift of the sample
+  static constexpr int GN_MAXC = CM_GN_MAXC;
   static constexpr int LDS_BYTES = GN_OFF + CM_GN_BYTES;
   static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
   static constexpr int ITEMS = P * Q;
@@ -627,7 +720,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
       c = c < a.Cin ? c : 0;
       if (gn_fold) {
         psc_r = *(const f32x4*)(gn_sc + c);
-        psh_r = *(const f32x4*)(gn_sc + CM_GN_MAXC + c);
+        psh_r = *(const f32x4*)(gn_sc + G::GN_MAXC + c);
       } else {
         psc_r = *(const f32x4*)(psc + c);
         psh_r = *(const f32x4*)(psh + c);
@@ -689,7 +782,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
 #pragma unroll
   for (int s = 0; s < G::RING - 1; ++s) fetch_b(s, s);
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
-    cm_gn_to_lds(a, b, tid, 256, (float*)(smem + G::GN_OFF));
+    cm_gn_to_lds(a, b, tid, 256, (float*)(smem + G::GN_OFF), G::GN_MAXC);
     __syncthreads();
   }
   fetch_ss(0);
@@ -972,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(mud_conv_args a, const 
 
 // split-K needs a plain epilogue and whole, aligned float4 channel columns (the reduce kernel's access pattern)
 static bool cm_split_eligible(const mud_conv_args& a) {
-  return a.ks == 3 && !a.sub2 && !a.emul && !a.egate && a.Cout % 4 == 0 && a.Cout <= 1024 && a.ldo % 4 == 0 && (!a.res || a.ldr % 4 == 0) &&
+  return a.ks == 3 && !a.skip_w && !a.sub2 && !a.emul && !a.egate && a.Cout % 4 == 0 && a.Cout <= 1024 && a.ldo % 4 == 0 && (!a.res || a.ldr % 4 == 0) &&
          mud_aligned16(a.out) && (!a.res || mud_aligned16(a.res)) && (!a.bias || mud_aligned16(a.bias)) &&
          (!a.bias2 || (mud_aligned16(a.bias2) && a.bias2_ld % 4 == 0));
 }
@@ -995,11 +1088,11 @@ static int cm_splits(int64_t blocks, int nchunks) {
   return ns;
 }
 
-template <int KS, int MT, int WM, int WN, int PRO>
+template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false>
 static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
-  using G = typename std::conditional<KS == 3, CmGeo<KS, MT, WM, WN>, CmGeoRegB<KS, MT>>::type;
+  using G = typename std::conditional<KS == 3, CmGeo<KS, MT, WM, WN, DUAL>, CmGeoRegB<KS, MT>>::type;
   const void* kfn;
-  if constexpr (KS == 3) kfn = (const void*)k_conv_mfma<KS, MT, WM, WN, PRO>;      // only the variant that is launched is instantiated
+  if constexpr (KS == 3) kfn = (const void*)k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>;      // only the variant that is launched is instantiated
   else kfn = (const void*)k_conv_mfma_regb<KS, MT, PRO>;
   static mud_attr_once attr_once;
   if (attr_once.need()) {
@@ -1024,7 +1117,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
     // split-K (small grids): needs the caller's slab workspace, a plain epilogue and whole float4 channel columns
     const int64_t npix = (int64_t)a.B * a.H * a.W;
     int ns = 1;
-    if (a.splitk_ws && mud_aligned16(a.splitk_ws) && cm_split_eligible(a)) ns = cm_splits(nblocks, k16s);
+    if (!DUAL && a.splitk_ws && mud_aligned16(a.splitk_ws) && cm_split_eligible(a)) ns = cm_splits(nblocks, k16s);
     if (ns > 1 && a.splitk_ws_bytes < (int64_t)ns * npix * a.Cout * 4) ns = 1;      // workspace too small: run unsplit
     if (ns > 1) {
       mud_conv_args p = a;                       // raw partial sums: no epilogue terms, output = slab ksi of the workspace
@@ -1035,7 +1128,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       p.act = MUD_ACT_NONE;
       p.stats = nullptr;
       const int64_t stride = npix * a.Cout;
-      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), G::LDS_BYTES, s, p, tiles_x,
+      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), G::LDS_BYTES, s, p, tiles_x,
                          (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, stride);
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K)");
       const int64_t HW = (int64_t)a.H * a.W;
@@ -1046,7 +1139,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K epilogue)");
       return MUD_OK;
     }
-    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO>), dim3((unsigned)nblocks), dim3(64 * WM * WN), G::LDS_BYTES, s, a, tiles_x, (int)tiles,
+    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)nblocks), dim3(64 * WM * WN), G::LDS_BYTES, s, a, tiles_x, (int)tiles,
                        ntiles, k16s, (unsigned)nblocks, 1, (int64_t)0);
   } else
     hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
@@ -1128,6 +1221,13 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
     a.pro_ld = 0;
     a.gn_sums = nullptr;
   }
+  if (a.skip_w) {
+    MUD_REQUIRE(a.ks == 3 && a.pro_mode == MUD_PRO_AFFINE_SILU && !a.res && !a.sub2 && !a.emul && !a.egate,
+                "mud_conv2d_mfma: the fused skip conv needs ks == 3, the AFFINE_SILU prologue and a plain epilogue");
+    MUD_REQUIRE(a.skip_out && a.Cin <= 512 && a.Cout % 4 == 0 && a.skip_ldo >= a.Cout && a.skip_ldo % 4 == 0 && a.ldo % 4 == 0 &&
+                mud_aligned16(a.skip_w) && mud_aligned16(a.skip_out) && mud_aligned16(a.out),
+                "mud_conv2d_mfma: fused skip conv needs Cin <= 512, Cout %% 4 == 0 and aligned float4 output rows (Cin=%d Cout=%d)", a.Cin, a.Cout);
+  }
   if (a.B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
   // tile height by problem size: big tiles (more MFMA work per weight byte) once they still fill the 256 CUs
@@ -1136,6 +1236,15 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   if (force_mt) {
     if (a.ks == 3) return (force_mt == 8 && ntiles % 2 == 0) ? cm_launch<3, 2, 4, 2>(a, s) : force_mt == 16 ? cm_launch<3, 2, 8, 1>(a, s) : force_mt == 1 ? cm_launch<3, 1>(a, s) : cm_launch<3, 2>(a, s);
     return cm_launch<1, 1>(a, s);      // (256- and 512-pixel 1x1 tiles were measured 5-8 % slower and are no longer built)
+  }
+  if (a.ks == 3 && a.skip_w) {
+    // fused 1x1 skip conv (DUAL): built for the AdaGN + SiLU prologue of the residual blocks only; the 8-row 4-wave tile would
+    // drop to one workgroup per CU with the second image, so small grids take the 4-row tile
+    switch (cm_variant3(a, nullptr)) {
+      case CMV_8X2: return cm_launch_pro<3, 2, 4, 2, MUD_PRO_AFFINE_SILU, true>(a, s);
+      case CMV_16X1: return cm_launch_pro<3, 2, 8, 1, MUD_PRO_AFFINE_SILU, true>(a, s);
+      default: return cm_launch_pro<3, 1, 4, 1, MUD_PRO_AFFINE_SILU, true>(a, s);
+    }
   }
   if (a.ks == 3) {
     switch (cm_variant3(a, nullptr)) {

@@ -43,6 +43,7 @@ class ConvArgs(C.Structure):
         ('gn_sums', C.c_void_p), ('gn_sums_ld', C.c_int), ('gn_G', C.c_int), ('gn_eps', C.c_float), ('gn_count', C.c_double),
         ('gn_gamma', C.c_void_p), ('gn_beta', C.c_void_p), ('gn_bstride', C.c_int64),
         ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
+        ('skip_w', C.c_void_p), ('skip_bias', C.c_void_p), ('skip_out', C.c_void_p), ('skip_ldo', C.c_int),
     ]
 
 

@@ -279,6 +279,14 @@ import os as _os
 FOLD_GN = _os.environ.get('MUD_FOLD_GN', '1') != '0'      # A/B knob: 0 = one gn_from_sums launch per GroupNorm (round-1 behaviour)
 
 
+FUSE_SKIP = _os.environ.get('MUD_FUSE_SKIP', '1') != '0'     # A/B knob: 0 = the 1x1 skip conv stays its own launch (round-1 behaviour)
+
+
+def fused_skip_ok(x: View, cout, pro_mode):
+    """Can mud_conv2d_mfma produce the block's 1x1 skip conv alongside its 3x3 conv (mud_conv_args.skip_*)?"""
+    return FUSE_SKIP and pro_mode == PRO_AFFINE_SILU and x.C % 4 == 0 and 8 <= x.C <= 512 and cout % 4 == 0
+
+
 def resolve_pro(pro):
     """(scale, shift, mode) with the arrays materialised (for consumers that cannot fold the GroupNorm finalisation)."""
     if pro is not None and isinstance(pro[0], LazyGN):
@@ -327,8 +335,11 @@ def direct_weight(w_oihw):
 
 
 def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None, bias2=None, res: View = None,
-         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None, sub2=False, emul: View = None, gate=None, emul_cout=0):
-    """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode)."""
+         out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None, sub2=False, emul: View = None, gate=None, emul_cout=0,
+         skip=None):
+    """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode).
+    skip = (packed 1x1 weights, bias or None, out View): the same launch also writes the 1x1 convolution of the RAW input
+    (the residual block's Conv_2) - see fused_skip_ok()."""
     lib = load()
     pad = ks // 2 if pad is None else pad
     Ho = (x.H + 2 * pad - ks) // stride + 1
@@ -381,6 +392,12 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
     if out.stats is not None:
         a.stats, a.stats_ld = out.stats_ptr, out.stats.shape[1]
+    skip_flops = 0.0
+    if skip is not None:
+        sw, sb, so = skip
+        assert mfma and ks == 3 and res is None and (so.B, so.H, so.W, so.C) == (x.B, Ho, Wo, Cout)
+        a.skip_w, a.skip_bias, a.skip_out, a.skip_ldo = ptr(sw), ptr(sb), so.ptr, so.ld
+        skip_flops = 2.0 * x.B * Ho * Wo * Cout * x.C
     if mfma and ks == 3:          # small grids (one slice at a time): split-K slabs, stream-ordered scratch (graph-capture safe)
         nws = lib.mud_conv2d_mfma_splitk_bytes(C.byref(a))
         if nws > 0:
@@ -388,7 +405,7 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
             a.splitk_ws, a.splitk_ws_bytes = ptr(keep[1]), nws
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
-    flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks     # algorithmic (sub2 issues 4x this)
+    flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks + skip_flops     # algorithmic (sub2 issues 4x this)
     nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * (2 if res is not None else 1)) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
     _launch(name, x.device, fn, C.byref(a), STREAM, flops=flops, nbytes=nbytes)
     return out

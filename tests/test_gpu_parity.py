@@ -249,6 +249,36 @@ def test_groupnorm_folded_into_conv_prologue(B, H, W, C, Cout, ks, silu):
     assert err <= 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 20, 37, 48, 96), (16, 64, 64, 384, 256), (8, 128, 128, 192, 64), (1, 64, 64, 512, 256), (2, 33, 70, 320, 64),
+                                            (3, 16, 16, 24, 40)])
+def test_conv_with_fused_skip_conv(B, H, W, Cin, Cout):
+    """mud_conv_args.skip_*: one launch = conv3x3(silu(affine(x))) + bias + time bias (with statistics) AND the residual block's
+    1x1 skip conv of the raw x (reference layerspp.py:311-321).  Both outputs against fp64, and the 3x3 output against the
+    unfused launch; covers the three tile variants (8x2, 16x1, 4-row) and ragged sizes."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / math.sqrt(Cin * 9)
+    w2 = torch.randn(Cout, Cin, 1, 1, generator=gen) / math.sqrt(Cin)
+    bias, bias_s, b2 = torch.randn(Cout, generator=gen), torch.randn(Cout, generator=gen), torch.randn(B, Cout, generator=gen)
+    sc, sh = torch.rand(B, Cin, generator=gen) + 0.5, torch.randn(B, Cin, generator=gen)
+    xv, wp, w2p = ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ops.pack_conv_weight(g(w2))
+    assert ops.fused_skip_ok(xv, Cout, ops.PRO_AFFINE_SILU)
+    arena = ops.StatsArena(torch.device(DEV))
+    out, skip = ops.View.empty(B, H, W, Cout, DEV, arena), ops.View.empty(B, H, W, Cout + 8, DEV).slice(4, Cout)
+    pro = (g(sc), g(sh), ops.PRO_AFFINE_SILU)
+    ops.conv(xv, wp, 3, Cout, mfma=True, pro=pro, bias=g(bias), bias2=g(b2), out=out, skip=(w2p, g(bias_s), skip))
+    plain = ops.conv(xv, wp, 3, Cout, mfma=True, pro=pro, bias=g(bias), bias2=g(b2))
+    assert maxdiff(out.to_nchw(), plain.to_nchw()) <= 2e-5         # (a small grid runs the unfused launch split-K: another summation order)
+    h = F.silu(x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None])
+    ref = F.conv2d(h, w.double(), bias.double(), padding=1) + b2.double()[:, :, None, None]
+    ref_s = F.conv2d(x.double(), w2.double(), bias_s.double())
+    e1, e2 = maxdiff(out.to_nchw(), ref), maxdiff(skip.to_nchw(), ref_s)
+    print(f'fused skip conv {B}x{H}x{W} {Cin}->{Cout}: 3x3 {e1:.2e}, 1x1 skip {e2:.2e} vs fp64')
+    assert e1 <= 1e-4 and e2 <= 1e-4
+    assert maxdiff(out.stats[..., 0], ref.sum(dim=(2, 3))) <= 2e-6 * float(ref.abs().sum(dim=(2, 3)).max())
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 64, 64, 256, 256), (1, 64, 64, 512, 256), (1, 32, 32, 384, 128), (1, 40, 24, 320, 64), (4, 64, 64, 256, 256)])
 def test_conv_split_k_small_grids(B, H, W, Cin, Cout):
     """Small grids (one slice at a time) deal the K chunks of a tile to several workgroups (raw partial slabs + a fixed-order
