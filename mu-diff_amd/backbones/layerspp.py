@@ -356,11 +356,12 @@ class ConvBlock(nn.Module, _Prepared):
             h = cache['h']
             if arena is not None:
                 h.stats = arena.take(h.B, h.C)
-                h.stats.copy_(cache['stats'])
+                if h.stats is not None:
+                    h.stats.copy_(cache['stats'])
         else:
             h = p['c1'](x, arena=arena)
-            if cache is not None and h.stats is not None:
-                cache.update(h=h, stats=h.stats.clone())
+            if cache is not None:
+                cache.update(h=h, stats=None if h.stats is None else h.stats.clone())
         gn = self.group_norm.scale_shift(h, style_out)
         sc, sh = (gn, None) if isinstance(gn, ops.LazyGN) else gn
         return p['c2'](h, pro=(sc, sh, PRO_AFFINE_SILU), out=out)

@@ -448,7 +448,8 @@ class _G1(_NCSNppBase):
                 buf = lc['buf']
                 buf.stats = arena.take(B, buf.C)
                 c0 = bufs[-1][1] + nf
-                buf.stats[:, c0:].copy_(lc['stats'])
+                if buf.stats is not None:
+                    buf.stats[:, c0:].copy_(lc['stats'])
                 bufs[-1] = (buf, bufs[-1][1], bufs[-1][2])
             hs0 = bufs[-1][0].slice(bufs[-1][1], bufs[-1][2])
             for j, (e, img) in enumerate(zip(feats, imgs)):
@@ -456,7 +457,8 @@ class _G1(_NCSNppBase):
                     continue
                 mods[e['idx']].run(img, out=hs0.slice(j * nf, nf), arena=arena)
             if lc is not None and not reuse:
-                lc.update(key=key, buf=bufs[-1][0], stats=bufs[-1][0].stats[:, bufs[-1][1] + nf:].clone())
+                st_ = bufs[-1][0].stats
+                lc.update(key=key, buf=bufs[-1][0], stats=None if st_ is None else st_[:, bufs[-1][1] + nf:].clone())
             return self._trunk(p, trunk, bufs, xv, temb, zemb, arena)
 
 
