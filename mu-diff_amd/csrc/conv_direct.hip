@@ -7,6 +7,7 @@
 // and acts as the exact fallback for any other shape.  One thread owns one output pixel and VO
 // consecutive output channels; the VO-wide weight rows are wave-uniform loads served by L1/L2.
 #include "mud_common.h"
+#include <stdlib.h>
 
 template <int VO, int VI>
 __global__ __launch_bounds__(256) void k_conv_direct(mud_conv_args a, int Ho, int Wo, int co_groups) {
@@ -284,7 +285,12 @@ extern "C" int mud_conv2d_direct(const mud_conv_args* ap, void* stream) {
       // every block ends with one fp64 atomic per channel on the SAME [b, channel] cells, and same-address atomics retire
       // one at a time (~150 ns each in L2): 512 blocks per image cost 79 us of a 133 us launch.  Keep about 2048 blocks
       // in total (8 per CU) and let each block walk more strips instead.
-      const int64_t per_image = 2048 / a.B > 16 ? 2048 / a.B : 16;
+      // At small batches the same holds per image: measured at 256x256 -> 64 channels (profiles/r02_e_head_blocks.txt), B = 1 / 2 / 4:
+      // 512 blocks per image 22.7 / 28.3 / 45.3 us, 256: 17.4 / 20.6 / 26.7 us, 128: 18.8 / 19.3 / 23.4 us, 64: 25.6 / 26.0 / 27.0 us.
+      static const int cap = getenv("MUD_HEAD_CAP") ? atoi(getenv("MUD_HEAD_CAP")) : 0;     // tuning knob
+      int64_t per_image = 2048 / a.B > 16 ? 2048 / a.B : 16;
+      const int64_t lim = cap > 0 ? cap : (a.B == 1 ? 256 : 128);
+      if (per_image > lim) per_image = lim;
       if (blocks > per_image) blocks = per_image;
     }
     if (a.stride == 1)

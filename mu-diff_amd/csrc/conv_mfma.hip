@@ -40,11 +40,14 @@
 #ifndef CM_FAKE16
 #define CM_FAKE16 0
 #endif
+#ifndef CM_PRE_RES_ALL
+#define CM_PRE_RES_ALL 0         // 1: the 4-wave tiles prefetch the residual tile too (experiment)
+#endif
 #define CM_BN 64
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
 #define CM_PIX 80                // LDS bytes per pixel record of the A tile
-#define CM_GN_MAXC 1024         // channels of the folded GroupNorm finalisation (scale | shift arrays in LDS: 8 KiB)
+#define CM_GN_MAXC 1024         // most channels the folded GroupNorm finalisation takes (scale | shift arrays in LDS: up to 8 KiB)
 #define CM_GN_BYTES (2 * CM_GN_MAXC * 4)
 
 template <int KS, int MT, int WM, int WN, bool DUAL = false>
@@ -69,19 +72,24 @@ struct CmGeo {
   static constexpr int PIECES = GB / 1024;              // 1 KiB DMA pieces per group
   static constexpr int A_BYTES = 2 * BUF;
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
-  static constexpr int GN_OFF = A_BYTES + 2 * GB;       // folded GroupNorm finalisation: scale | shift of the sample
   static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
   // DUAL (3x3 conv + the block's 1x1 skip conv of the RAW input from one staging pass, see k_conv_mfma): a second, single-
   // buffered A image of the tile's centre pixels [hi 32 B | lo 32 B] (64-B records, 16-B units XOR-swizzled by the column)
   // and one slot for the 1x1 weights of the current chunk.  The GroupNorm arrays shrink to 512 channels to make room.
   static constexpr int GN_MAXC = DUAL ? 512 : CM_GN_MAXC;
-  static constexpr int A2_OFF = GN_OFF + 2 * GN_MAXC * 4;
+  static constexpr int A2_OFF = A_BYTES + 2 * GB;
   static constexpr int A2_BYTES = DUAL ? ROWS * 32 * 64 : 0;
   static constexpr int B2_OFF = A2_OFF + A2_BYTES;
   static constexpr int B2_BYTES = DUAL ? WN * CM_BSTEP : 0;
-  static constexpr int MAIN_BYTES = B2_OFF + B2_BYTES;
-  static constexpr int LDS_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  // folded GroupNorm finalisation: scale | shift of the sample, 2 x roundup4(Cin) floats at the END of the image, requested
+  // per launch (a fixed 8 KiB here would push the 8-row 4-wave tile over 80 KiB = from two workgroups per CU to one)
+  static constexpr int GN_OFF = B2_OFF + B2_BYTES;
+  static constexpr int LDS_MAX = (GN_OFF + 2 * GN_MAXC * 4) > EP_BYTES ? (GN_OFF + 2 * GN_MAXC * 4) : EP_BYTES;
+  static constexpr int lds_bytes(int gn_channels) {
+    const int m = GN_OFF + 8 * ((gn_channels + 3) & ~3);
+    return m > EP_BYTES ? m : EP_BYTES;
+  }
+  static_assert(LDS_MAX <= 160 * 1024, "LDS budget");
   static_assert(NT % Q == 0, "staging split");
 };
 
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
   const bool gn_fold = (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) && a.gn_sums != nullptr;   // workgroup-uniform
   const float* const gn_sc = (const float*)(smem + G::GN_OFF);
+  const int gn_c = (a.Cin + 3) & ~3;            // shift array follows the scale array
   auto fetch_raw = [&](int chunk) {
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
       c = c < a.Cin ? c : 0;
       if (gn_fold) {
         psc_r = *(const f32x4*)(gn_sc + c);
-        psh_r = *(const f32x4*)(gn_sc + G::GN_MAXC + c);
+        psh_r = *(const f32x4*)(gn_sc + gn_c + c);
       } else {
         psc_r = *(const f32x4*)(psc + c);
         psh_r = *(const f32x4*)(psh + c);
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   dma_b2(kc0);
   fetch_raw(kc0);
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
-    cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF), G::GN_MAXC);
+    cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF), gn_c);
     __syncthreads();
   }
   fetch_ss(kc0);
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
-  const bool pre_res = !DUAL && KS == 3 && WM * WN >= 8 && a.res && vec && !a.sub2;      // (the 4-wave variants have no registers to spare; DUAL has no residual)
+  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || WM * WN >= 8) && a.res && vec && !a.sub2;      // (DUAL has no residual)
   f32x4 rpre[2][MT][4];
   const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
   auto prefetch_res = [&]() {
@@ -635,9 +644,10 @@ struct CmGeoRegB {
   static constexpr int P = (KS == 3) ? (ROWS + 2) * PW : 128 * MT;
   static constexpr int PLANE = P * CM_PIX;              // P pixel records [hi 32 B | lo 32 B | pad 16 B]
   static constexpr int BUF = CH * PLANE;                // [k16 s]
-  static constexpr int GN_OFF = 2 * BUF;                // folded GroupNorm finalisation: scale | shift of the sample
+  static constexpr int GN_OFF = 2 * BUF;                // folded GroupNorm finalisation: scale | shift of the sample (sized per launch)
   static constexpr int GN_MAXC = CM_GN_MAXC;
-  static constexpr int LDS_BYTES = GN_OFF + CM_GN_BYTES;
+  static constexpr int LDS_MAX = GN_OFF + CM_GN_BYTES;
+  static constexpr int lds_bytes(int gn_channels) { return GN_OFF + 8 * ((gn_channels + 3) & ~3); }
   static constexpr int Q = 4 * CH;                      // float4 per pixel per chunk
   static constexpr int ITEMS = P * Q;
   static constexpr int NLOAD = (ITEMS + 255) / 256;
@@ -708,6 +718,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
   f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
   const bool gn_fold = (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) && a.gn_sums != nullptr;   // workgroup-uniform
   const float* const gn_sc = (const float*)(smem + G::GN_OFF);
+  const int gn_c = (a.Cin + 3) & ~3;            // shift array follows the scale array
   auto fetch_raw = [&](int chunk) {
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
       c = c < a.Cin ? c : 0;
       if (gn_fold) {
         psc_r = *(const f32x4*)(gn_sc + c);
-        psh_r = *(const f32x4*)(gn_sc + G::GN_MAXC + c);
+        psh_r = *(const f32x4*)(gn_sc + gn_c + c);
       } else {
         psc_r = *(const f32x4*)(psc + c);
         psh_r = *(const f32x4*)(psh + c);
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
 #pragma unroll
   for (int s = 0; s < G::RING - 1; ++s) fetch_b(s, s);
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
-    cm_gn_to_lds(a, b, tid, 256, (float*)(smem + G::GN_OFF), G::GN_MAXC);
+    cm_gn_to_lds(a, b, tid, 256, (float*)(smem + G::GN_OFF), gn_c);
     __syncthreads();
   }
   fetch_ss(0);
@@ -1096,13 +1107,14 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   else kfn = (const void*)k_conv_mfma_regb<KS, MT, PRO>;
   static mud_attr_once attr_once;
   if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_MAX);
     if (e != hipSuccess) {
-      mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
+      mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_MAX, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
   }
   const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN * WN);
+  const int lds = G::lds_bytes(a.gn_sums ? a.Cin : 0);
   int tiles_x = 1;
   int64_t tiles;
   if (KS == 3) {
@@ -1128,7 +1140,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       p.act = MUD_ACT_NONE;
       p.stats = nullptr;
       const int64_t stride = npix * a.Cout;
-      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), G::LDS_BYTES, s, p, tiles_x,
+      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, p, tiles_x,
                          (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, stride);
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K)");
       const int64_t HW = (int64_t)a.H * a.W;
@@ -1139,10 +1151,10 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K epilogue)");
       return MUD_OK;
     }
-    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)nblocks), dim3(64 * WM * WN), G::LDS_BYTES, s, a, tiles_x, (int)tiles,
+    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)nblocks), dim3(64 * WM * WN), lds, s, a, tiles_x, (int)tiles,
                        ntiles, k16s, (unsigned)nblocks, 1, (int64_t)0);
   } else
-    hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), G::LDS_BYTES, s, a, tiles_x, (int)tiles, ntiles, k16s,
+    hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), lds, s, a, tiles_x, (int)tiles, ntiles, k16s,
                        (unsigned)nblocks);
   MUD_CHECK_LAUNCH("mud_conv2d_mfma");
   return MUD_OK;

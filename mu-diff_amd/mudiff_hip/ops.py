@@ -416,7 +416,7 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks + skip_flops     # algorithmic (sub2 issues 4x this)
-    nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * (2 if res is not None else 1)) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
+    nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * ((2 if res is not None else 1) + (1 if skip is not None else 0))) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
     _launch(name, x.device, fn, C.byref(a), STREAM, flops=flops, nbytes=nbytes)
     return out
 

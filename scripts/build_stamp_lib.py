@@ -5,11 +5,12 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'mu-diff_amd', 'csrc')
 s = open(os.path.join(CSRC, 'conv_mfma.hip')).read()
-s = s.replace("template <int KS, int MT, int WM, int WN>\nstruct CmGeo {", '''__device__ unsigned long long g_stamps[64 * 64];
+s = s.replace("template <int KS, int MT, int WM, int WN, bool DUAL = false>\nstruct CmGeo {", '''__device__ unsigned long long g_stamps[64 * 64];
 extern "C" int mud_debug_read_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 #define STAMP(i) do { if (tid == 0 && blockIdx.x < 64 && (i) < 64) g_stamps[blockIdx.x * 64 + (i)] = ((i) == 58 || (i) == 59) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
-template <int KS, int MT, int WM, int WN>
+template <int KS, int MT, int WM, int WN, bool DUAL = false>
 struct CmGeo {''', 1)
+assert "define STAMP" in s
 k0, k1 = s.index("void k_conv_mfma(mud_conv_args a"), s.index("// Variant for ks == 1")
 b = s[k0:k1]
 
