@@ -40,6 +40,10 @@
 #ifndef CM_FAKE16
 #define CM_FAKE16 0
 #endif
+#ifndef CM_WHATIF
+#define CM_WHATIF 0              // TIMING PROBES (wrong results): 1 = no prologue arithmetic in the staging, 2 = no activation loads,
+#endif                           // 3 = no weight DMA, 4 = no MFMAs, 5 = no staging at all (no loads, no arithmetic, no LDS writes),
+                                 // 6 / 7 / 8 = fragment reads only in the first tap of a 3-tap group: all / A only kept / B only kept
 #ifndef CM_PRE_RES_ALL
 #define CM_PRE_RES_ALL 0         // 1: the 4-wave tiles prefetch the residual tile too (experiment)
 #endif
@@ -214,6 +218,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   auto fetch_raw = [&](int chunk) {
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
+#if CM_WHATIF == 2 || CM_WHATIF == 5
+    if (chunk != kc0) return;
+#endif
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
   };
@@ -236,11 +243,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   };
   auto store_a_slots = [&](int chunk, char* buf, int j0, int j1) {
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
+#if CM_WHATIF == 5
+    if (chunk != kc0) return;
+#endif
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
       if (j < j0 || j >= j1) continue;
       f32x4 v = raw[j];
-      if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
+      if (CM_WHATIF != 1 && (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU)) {
         v = v * psc_r + psh_r;
         if (PRO == MUD_PRO_AFFINE_SILU) {
 #pragma unroll
@@ -278,6 +288,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   char* const bring = smem + G::B_OFF;
   auto dma_b = [&](int gg) {                    // group gg -> ring slot gg & 1
     if (gg >= total_groups) return;             // wave-uniform
+#if CM_WHATIF == 3
+    if (gg > kc0 * G::NG + 1) return;
+#endif
     char* dst = bring + (gg & 1) * G::GB;
 #pragma unroll
     for (int j = 0; j < (G::PIECES + WM * WN - 1) / (WM * WN); ++j) {
@@ -364,6 +377,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
 #if CM_PRIO == 1
   if (late_half) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every arbitration by age: static priority instead
 #endif
+#if CM_WHATIF >= 6
+  bf16x8 wbh[2] = {}, wbl[2] = {}, wah[MT] = {}, wal[MT] = {};
+#endif
   for (int kc = kc0; kc < nchunks; ++kc) {
     char* cur = smem + (kc & 1) * G::BUF;
     char* nxt = smem + ((kc + 1) & 1) * G::BUF;
@@ -420,18 +436,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
         const int tap = (KS == 3) ? st : 0;
         const int dy = tap / KS, dx = tap % KS;
         if (kc * G::CH + s < k16s) {
+#if CM_WHATIF >= 6
+          // stale-fragment probes: 6 = no fragment reads after the first tap of a group, 7 = no B reads, 8 = no A reads
+          if (sg == 0 || CM_WHATIF == 8) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              wbh[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + n * 1024 + lane_b);
+              wbl[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
+            }
+          }
+          bf16x8 bh[2] = {wbh[0], wbh[1]}, bl[2] = {wbl[0], wbl[1]};
+#else
           bf16x8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
             bh[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + n * 1024 + lane_b);
             bl[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
           }
+#endif
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             // lane base (wave row, column r, k half hh) + compile-time (m, tap, s) offset
             const int off = s * G::PLANE + ((KS == 3) ? ((m + dy) * G::PW + dx) : (m * 32)) * CM_PIX;
+#if CM_WHATIF >= 6
+            if (sg == 0 || CM_WHATIF == 7) {
+              wah[m] = *(const bf16x8*)(cur + lane_a + off);
+              wal[m] = *(const bf16x8*)(cur + lane_a + off + 32);
+            }
+            const bf16x8 ah = wah[m], al = wal[m];
+#else
             const bf16x8 ah = *(const bf16x8*)(cur + lane_a + off);
             const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
+#endif
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
 #if CM_FAKE16
@@ -449,6 +485,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
               q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], q[2], 0, 0, 0);
 #pragma unroll
               for (int i = 0; i < 16; ++i) acc[m][n][i] = q[i >> 2][i & 3];
+#elif CM_WHATIF == 4
+              asm volatile("" :: "v"(al), "v"(ah), "v"(bh[n]), "v"(bl[n]));      // keep the fragment reads alive
 #else
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc[m][n], 0, 0, 0);
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
