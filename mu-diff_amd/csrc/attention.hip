@@ -15,6 +15,7 @@
 // K / V tiles of 32 keys are double-buffered in LDS; the next tile's global loads are in flight (registers)
 // during the MFMAs of the current one; one barrier per tile.
 #include "mud_common.h"
+#include <stdlib.h>
 
 template <int C16>
 struct AtGeo {
@@ -255,6 +256,247 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Channel-split pair variant for C >= 128 (two waves per SIMD).  k_attention keeps Q (2*C/16 fragments) and the C x 32 output
+// accumulator of a 32-query column in ONE wave: 511 VGPRs, one wave per SIMD, so the softmax / staging arithmetic of a wave
+// runs with its SIMD's matrix pipe idle (the key loop spent about two thirds of its cycles outside MFMAs).  Here a 32-query
+// column is owned by a PAIR of waves (w, w + 4), each with half of the channels:
+//     partial S^T = K[:, my half of C] . Q^T[my half]      24 MFMAs of the 48 (C = 256)
+//     exchange the two partial tiles through LDS (4 KiB per wave), one barrier, add            -> the full S^T in both waves
+//     online softmax (both waves, identical values), P^T fragments from the accumulator registers as before
+//     O^T[my half of C] += V^T[my half] . P^T              24 MFMAs of the 48
+// Registers per wave halve (Q 64 + O 64), the workgroup has 8 waves = 2 per SIMD, and the K / V staging work is spread over
+// 512 threads.  K tiles stay double-buffered; the V tile is single-buffered (a second barrier per key tile orders its refill
+// behind the last P.V read) to leave LDS room for the exchange slots.
+template <int C16>
+struct At2Geo {
+  static_assert(C16 % 4 == 0 && C16 >= 8, "pair variant: C in {128, 256}");
+  static constexpr int C = 16 * C16;
+  static constexpr int H16 = C16 / 2;                 // k16 steps of a wave's channel half
+  static constexpr int CTH = C16 / 4;                 // 32-channel output tiles of a wave's half
+  static constexpr int KROW = C * 4 + 16;             // LDS bytes per key row: [hi C x bf16 | lo C x bf16 | pad]
+  static constexpr int VROW = 144;                    // LDS bytes per channel row: [hi 32 keys | lo 32 keys | pad]
+  static constexpr int KT = 32 * KROW, VT = C * VROW;
+  static constexpr int V_OFF = 2 * KT, X_OFF = V_OFF + VT;
+  static constexpr int LDS_BYTES = X_OFF + 8 * 4096;
+  static constexpr int KN = (32 * (C / 4)) / 512;     // float4 loads per thread for a K tile
+  static constexpr int VN = (C * 8) / 512;            // 4-key groups per thread for a V tile
+  static_assert(KN * 512 == 32 * (C / 4) && VN * 512 == C * 8, "staging split");
+};
+
+template <int C16>
+__global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restrict__ qkv, int N, int ld, float scale_log2,
+                                                            float* __restrict__ out, int ldo, int tiles_per_split, float* __restrict__ part) {
+  using G = At2Geo<C16>;
+  constexpr int C = G::C, H16 = G::H16, CTH = G::CTH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int pair = wave & 3, half = wave >> 2;                  // query column of the pair, channel half of this wave
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * 128 + pair * 32 + r;
+  const float* base = qkv + (int64_t)b * N * ld;
+  const int kt0 = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, kt0 + tiles_per_split);
+
+  // ---- Q^T B-fragments of this wave's channel half
+  bf16x8 qh[H16], ql[H16];
+#pragma unroll
+  for (int s = 0; s < H16; ++s) {
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (qi < N) {
+      const float* qp = base + (int64_t)qi * ld + 16 * (half * H16 + s) + 8 * hh;
+      v0 = *(const f32x4*)qp;
+      v1 = *(const f32x4*)(qp + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
+      qh[s][e] = h0; qh[s][4 + e] = h1;
+      ql[s][e] = (__bf16)(v0[e] - (float)h0); ql[s][4 + e] = (__bf16)(v1[e] - (float)h1);
+    }
+  }
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((int64_t)N * ld * 4 < 0x7fffffffLL ? (int64_t)N * ld * 4 : 0x7fffffffLL), 0x00020000);
+  constexpr int KJ = 512 / (C / 4);                    // key rows covered by one pass of the 512 threads (K stream)
+  constexpr int VG = 512 / C;                          // 4-key groups covered by one pass (V stream)
+  const unsigned kvoff = (unsigned)(((tid / (C / 4)) * ld + C + 4 * (tid % (C / 4))) * 4);
+  const unsigned vvoff = (unsigned)((2 * C + (tid % C)) * 4 + (4 * (tid / C)) * ld * 4);
+  f32x4 kraw[G::KN];
+  float vraw[G::VN][4];
+  auto fetch_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < G::KN; ++i)
+      kraw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff, (kt * 32 + KJ * i) * ld * 4, 0));   // keys >= N read 0
+  };
+  auto fetch_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < G::VN; ++i)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        vraw[i][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vvoff, (kt * 32 + 4 * VG * i + u) * ld * 4, 0));
+  };
+  auto stash_k = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < G::KN; ++i) {
+      const int item = tid + 512 * i, j = item / (C / 4), c4 = item % (C / 4);
+      const bf16x4 hi = __builtin_convertvector(kraw[i], bf16x4);
+      const bf16x4 lo = __builtin_convertvector(kraw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+      *(bf16x4*)(buf + j * G::KROW + c4 * 8) = hi;
+      *(bf16x4*)(buf + j * G::KROW + C * 2 + c4 * 8) = lo;
+    }
+  };
+  auto stash_v = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::VN; ++i) {
+      const int item = tid + 512 * i, c = item % C, g = item / C;
+      // keys 4g..4g+3 of the tile -> k-step s, lane half h, element block: the order in which the S^T accumulator
+      // registers enumerate keys (element e of half h of step s is key 16s + 8(e>>2) + 4h + (e&3))
+      const int jj = (4 * g) & 15, s = (4 * g) >> 4, h = (jj >> 2) & 1, blk = (jj >> 3) & 1;
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const __bf16 t = (__bf16)vraw[i][u];
+        hi[u] = t;
+        lo[u] = (__bf16)(vraw[i][u] - (float)t);
+      }
+      char* p = smem + G::V_OFF + c * G::VROW + s * 32 + h * 16 + blk * 8;
+      *(bf16x4*)p = hi;
+      *(bf16x4*)(p + 64) = lo;
+    }
+  };
+
+  f32x16 o[CTH];
+#pragma unroll
+  for (int ct = 0; ct < CTH; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[ct][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4* const xmine = (f32x4*)(smem + G::X_OFF + wave * 4096) + lane;          // [4 register quads][64 lanes] of 16 B
+  const f32x4* const xpeer = (const f32x4*)(smem + G::X_OFF + (wave ^ 4) * 4096) + lane;
+
+  fetch_k(kt0);
+  stash_k(smem);
+  fetch_v(kt0);
+  stash_v();
+  __syncthreads();
+
+  for (int kt = kt0; kt < ntiles; ++kt) {
+    const char* cur = smem + ((kt - kt0) & 1) * G::KT;
+    char* nxt = smem + ((kt - kt0 + 1) & 1) * G::KT;
+    const bool more = kt + 1 < ntiles;
+    if (more) fetch_k(kt + 1);
+
+    // ---- partial S^T over this wave's channel half
+    f32x16 st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < H16; ++s) {
+      const char* kp = cur + r * G::KROW + (16 * (half * H16 + s) + 8 * hh) * 2;
+      const bf16x8 kh = *(const bf16x8*)kp;
+      const bf16x8 kl = *(const bf16x8*)(kp + C * 2);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) xmine[q4 * 64] = f32x4{st[4 * q4], st[4 * q4 + 1], st[4 * q4 + 2], st[4 * q4 + 3]};
+    if (more) {
+      stash_k(nxt);                     // (its last readers passed the previous tile's barriers)
+      fetch_v(kt + 1);                  // in flight during softmax + P.V, parked in LDS behind the second barrier
+    }
+    __syncthreads();                    // the partner's partial tile is visible
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 p = xpeer[q4 * 64];
+      // the two halves are always added in the same order (low channels + high channels) so that both waves of the
+      // pair hold bit-identical scores
+      if (half == 0) { st[4 * q4] += p[0]; st[4 * q4 + 1] += p[1]; st[4 * q4 + 2] += p[2]; st[4 * q4 + 3] += p[3]; }
+      else { st[4 * q4] = p[0] + st[4 * q4]; st[4 * q4 + 1] = p[1] + st[4 * q4 + 1]; st[4 * q4 + 2] = p[2] + st[4 * q4 + 2]; st[4 * q4 + 3] = p[3] + st[4 * q4 + 3]; }
+    }
+
+    // ---- online softmax over the 32 keys of the tile (log2 domain); register i of half hh is key (i&3)+8(i>>2)+4hh
+    float mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      st[i] = key < N ? st[i] * scale_log2 : -INFINITY;
+      mt = fmaxf(mt, st[i]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = __builtin_amdgcn_exp2f(st[i] - m_new);
+      psum += st[i];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int ct = 0; ct < CTH; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[ct][i] *= alpha;
+    }
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float p = st[8 * s2 + e];
+        const __bf16 t = (__bf16)p;
+        ph[s2][e] = t;
+        pl[s2][e] = (__bf16)(p - (float)t);
+      }
+
+    // ---- O^T[my channel half] += V^T . P^T
+#pragma unroll
+    for (int ct = 0; ct < CTH; ++ct) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const char* vp = smem + G::V_OFF + ((half * CTH + ct) * 32 + r) * G::VROW + s2 * 32 + hh * 16;
+        const bf16x8 vh = *(const bf16x8*)vp;
+        const bf16x8 vl = *(const bf16x8*)(vp + 64);
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[ct], 0, 0, 0);
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[ct], 0, 0, 0);
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[ct], 0, 0, 0);
+      }
+    }
+    __syncthreads();                    // every wave is done with the V tile (and with its partner's exchange slot)
+    if (more) stash_v();                // ordered before the next P.V by the next tile's first barrier
+  }
+
+  // ---- normalise and store this wave's channel half
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (part) {
+    if (qi < N) {
+      float* pp = part + (((int64_t)b * gridDim.z + blockIdx.z) * N + qi) * (C + 4);
+#pragma unroll
+      for (int ct = 0; ct < CTH; ++ct)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int c0 = (half * CTH + ct) * 32 + 8 * q4 + 4 * hh;
+          *(f32x4*)(pp + c0) = f32x4{o[ct][4 * q4], o[ct][4 * q4 + 1], o[ct][4 * q4 + 2], o[ct][4 * q4 + 3]};
+        }
+      if (hh == 0 && half == 0) { pp[C] = m_run; pp[C + 1] = l_tot; }
+    }
+    return;
+  }
+  const float inv = 1.0f / l_tot;
+  if (qi < N) {
+    float* op = out + ((int64_t)b * N + qi) * ldo;
+#pragma unroll
+    for (int ct = 0; ct < CTH; ++ct)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int c0 = (half * CTH + ct) * 32 + 8 * q4 + 4 * hh;
+        *(f32x4*)(op + c0) = f32x4{o[ct][4 * q4] * inv, o[ct][4 * q4 + 1] * inv, o[ct][4 * q4 + 2] * inv, o[ct][4 * q4 + 3] * inv};
+      }
+  }
+}
+
 // out[b, q, :] = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s,  m = max_s m_s   (one thread per 4 channels)
 __global__ __launch_bounds__(256) void k_attention_combine(const float* __restrict__ part, int N, int C, int nsplit, float* __restrict__ out, int ldo) {
   const int C4 = C / 4;
@@ -287,6 +529,30 @@ static int at_splits(int B, int N) {
   if (ns < 1) ns = 1;
   const int tps = (int)mud_cdiv(ntiles, ns);
   return (int)mud_cdiv(ntiles, tps);                  // no empty split
+}
+
+template <int C16>
+static int at_launch_pair(const float* qkv, int B, int N, int ld, float scale, float* out, int ldo, float* ws, hipStream_t s) {
+  using G = At2Geo<C16>;
+  static mud_attr_once attr_once;
+  if (attr_once.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_attention_pair<C16>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      mud_set_error("mud_attention: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
+      return MUD_ERR_LAUNCH;
+    }
+  }
+  const int ntiles = (int)mud_cdiv(N, 32);
+  const int ns = ws ? at_splits(B, N) : 1;
+  const int tps = (int)mud_cdiv(ntiles, ns);
+  hipLaunchKernelGGL((k_attention_pair<C16>), dim3((unsigned)mud_cdiv(N, 128), B, ns), dim3(512), G::LDS_BYTES, s, qkv, N, ld,
+                     scale * 1.44269504088896340736f, out, ldo, tps, ns > 1 ? ws : (float*)nullptr);
+  MUD_CHECK_LAUNCH("mud_attention(pair)");
+  if (ns > 1) {
+    hipLaunchKernelGGL(k_attention_combine, dim3((unsigned)mud_cdiv((int64_t)N * (G::C / 4), 256), B), dim3(256), 0, s, ws, N, G::C, ns, out, ldo);
+    MUD_CHECK_LAUNCH("mud_attention(combine)");
+  }
+  return MUD_OK;
 }
 
 template <int C16>
@@ -328,11 +594,12 @@ extern "C" int mud_attention(const float* qkv, int B, int N, int C, int ld, floa
   MUD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && mud_aligned16(qkv) && mud_aligned16(out) && mud_aligned16(ws), "mud_attention: needs ld %% 4 == 0 and 16-byte aligned buffers");
   if (B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
+  static const bool at_pair = !(getenv("MUD_ATT_SINGLE") && atoi(getenv("MUD_ATT_SINGLE")));   // A/B knob: 1 = the one-wave-per-column kernel for every C
   switch (C) {
     case 16: return at_launch<1>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
     case 32: return at_launch<2>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
     case 64: return at_launch<4>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
-    case 128: return at_launch<8>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
-    default: return at_launch<16>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
+    case 128: return at_pair ? at_launch_pair<8>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s) : at_launch<8>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
+    default: return at_pair ? at_launch_pair<16>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s) : at_launch<16>(qkv, B, N, ld, scale, out, ldo, (float*)ws, s);
   }
 }
