@@ -436,12 +436,18 @@ def worker(a):
     if os.environ.get('MUDIFF_BENCH_DRYRUN') == '1':
         return dryrun_worker(a, rank, world)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU fallback for the HIP path'
+    if os.environ.get('MUDIFF_BENCH_SAME_GPU') == '1':      # rehearsal of the N-rank path on a one-GPU box (with MUDIFF_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ranks_seen = [0]
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)   # nccl == RCCL on ROCm
+        backend = os.environ.get('MUDIFF_BENCH_BACKEND', 'nccl')                       # nccl == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, init_method='env://')
         assert dist.get_world_size() == a.gpus
         got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(got, torch.tensor([rank], dtype=torch.int64, device=dev))

@@ -94,7 +94,7 @@ def test_batched_driver_vs_oracle_with_injected_draws(tmp_path):
     g1.load_state_dict(sd1); g2.load_state_dict(sd2)
     g1, g2 = g1.cuda().eval(), g2.cuda().eval()
     dev = torch.device('cuda:0')
-    for target in ('T1CE', 'T2'):                      # two of the four ORDERS (the other two: CPU test above)
+    for target in ('T1CE', 'FLAIR', 'T2', 'T1'):        # all four contrast orderings (reference dataset/dataset_brats.py:29-34)
         src = driver.SliceSource('test', str(tmp_path), target)
         x_init, zs, noises, draws = _draws_for(cfg, 7, 32)
         lo, preds, gts = driver.sample_slices(cfg, g1, g2, src, 4, dev, draws=draws)
