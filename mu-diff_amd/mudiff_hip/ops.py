@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -11,12 +12,11 @@ from . import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE,
                MudiffHipError, check, load, ptr, require_gpu)
 
 
-import os as _os0
 # MUD_DETERMINISTIC=1: bit-stable outputs run to run.  The only order-dependent arithmetic of the path is the fp64 atomic
 # accumulation of the GroupNorm (sum, sumsq) in the producers' epilogues (~1e-6 jitter on the outputs); with this switch the
 # producers accumulate nothing and every GroupNorm re-reads its input with per-workgroup partials + a fixed-order finalize
 # (mud_gn_scale_shift).  The reference's CPU path is deterministic; this costs one extra pass over each normalised tensor.
-DETERMINISTIC = _os0.environ.get('MUD_DETERMINISTIC', '0') == '1'
+DETERMINISTIC = os.environ.get('MUD_DETERMINISTIC', '0') == '1'
 
 
 class StatsArena:
@@ -285,11 +285,10 @@ def gn_lazy(x: View, G, gamma=None, beta=None, eps=1e-6):
     return LazyGN(x, G, gamma, beta, bstride, eps)
 
 
-import os as _os
-FOLD_GN = _os.environ.get('MUD_FOLD_GN', '1') != '0'      # A/B knob: 0 = one gn_from_sums launch per GroupNorm (round-1 behaviour)
+FOLD_GN = os.environ.get('MUD_FOLD_GN', '1') != '0'      # A/B knob: 0 = one gn_from_sums launch per GroupNorm (round-1 behaviour)
 
 
-FUSE_SKIP = _os.environ.get('MUD_FUSE_SKIP', '1') != '0'     # A/B knob: 0 = the 1x1 skip conv stays its own launch (round-1 behaviour)
+FUSE_SKIP = os.environ.get('MUD_FUSE_SKIP', '1') != '0'     # A/B knob: 0 = the 1x1 skip conv stays its own launch (round-1 behaviour)
 
 
 def fused_skip_ok(x: View, cout, pro_mode):
@@ -364,7 +363,7 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
     a.x, a.B, a.H, a.W, a.Cin, a.ldx = x.ptr, x.B, x.H, x.W, x.C, x.ld
     a.w, a.w_bstride = ptr(w), w_bstride
     a.ks, a.stride, a.pad = ks, stride, pad
-    keep = None
+    keep = None          # tensors the launch reads that nothing else references (lazy GroupNorm operands, split-K slabs)
     if pro is not None and isinstance(pro[0], LazyGN) and not (mfma and x.C <= 1024 and pro[0].x.stats is not None):
         pro = resolve_pro(pro)
     if pro is not None and pro[2] == PRO_LRELU:
