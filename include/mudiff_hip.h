@@ -68,6 +68,21 @@ int mud_pixel_norm(const float* z, float* out, int B, int K, void* stream);
 int mud_dense(const float* in, int ldi, const float* W, const float* bias, float* out, int ldo,
               int B, int K, int N, int act_in, int act_out, void* stream);
 
+/* A chain of dense layers in one launch (one workgroup per sample):  h = [pixel_norm](x);  for l: h = W[l] h + b[l], with
+ * `act` applied between layers (and after the last one iff act_last).  The z-mapping network (PixelNorm, dense(nz, z_emb),
+ * SiLU, n_mlp x [dense, SiLU]; ncsnpp_generator_adagn_feat.py:44-49,271-277) is {pixel_norm=1, act=SILU, act_last=1}; the
+ * timestep MLP (:301-305: Linear, SiLU, Linear) is {act=SILU, act_last=0}.  W[l]: [dims[l+1], dims[l]] row-major (nn.Linear). */
+#define MUD_MLP_MAX_LAYERS 6
+typedef struct mud_mlp_args {
+  const float* x; int ldx; int B;
+  int nlayers; int dims[MUD_MLP_MAX_LAYERS + 1];
+  const float* W[MUD_MLP_MAX_LAYERS]; const float* b[MUD_MLP_MAX_LAYERS];
+  int pixel_norm; int act; int act_last;
+  float* out; int ldo;
+  int maxdim;                                    /* filled in by the library */
+} mud_mlp_args;
+int mud_mlp_chain(const mud_mlp_args* a, void* stream);
+
 /* ---- GroupNorm statistics -> per-(sample, channel) scale/shift for a consumer's prologue
  *      (torch native_group_norm as used by backbones/layerspp.py:37-65,103, eps 1e-6, biased var).
  * scale[b,c] = gamma[b,c] * rstd[b,g(c)],  shift[b,c] = beta[b,c] - mean[b,g(c)] * scale[b,c]

@@ -253,11 +253,9 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
 
     def _embeddings(self, time_cond, z):
         mods = self.all_modules
-        h = ops.pixel_norm(z.float())
-        for layer in self.z_transform:
-            if isinstance(layer, nn.Linear):
-                h = ops.dense(h, layer.weight.detach(), layer.bias.detach(), act_out=ACT_SILU)
-        zemb = h
+        # PixelNorm + the whole z-mapping MLP in one launch (SiLU after every layer, reference :271-277)
+        zemb = ops.mlp_chain(z, [(m.weight, m.bias) for m in self.z_transform if isinstance(m, nn.Linear)], pixel_norm=True,
+                             act=ACT_SILU, act_last=True)
         if self.embedding_type == 'fourier':      # Gaussian Fourier features of log(sigma) (reference :286-290)
             temb = mods[self._plan[0]['idx']].run_log(time_cond)
         else:
@@ -265,8 +263,7 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
         if not self.conditional:
             return None, zemb
         l0, l1 = (mods[e['idx']] for e in self._plan if e['kind'] == 'temb')
-        temb = ops.dense(temb, l0.weight.detach(), l0.bias.detach())
-        temb = ops.dense(temb, l1.weight.detach(), l1.bias.detach(), act_in=ACT_SILU)
+        temb = ops.mlp_chain(temb, [(l0.weight, l0.bias), (l1.weight, l1.bias)], act=ACT_SILU, act_last=False)     # Linear, SiLU, Linear (:301-305)
         return temb, zemb
 
     def _check_inputs(self, x, conds, pseudo=None):

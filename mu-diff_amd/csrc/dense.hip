@@ -6,6 +6,8 @@
 
 #define DENSE_BCHUNK 8
 
+__device__ __forceinline__ bool mud_dev_aligned16f(const float* p) { return (((uintptr_t)p) & 15u) == 0; }
+
 __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ in, int ldi, const float* __restrict__ W,
                                                const float* __restrict__ bias, float* __restrict__ out, int ldo, int B, int K,
                                                int N, int act_in, int act_out) {
@@ -107,5 +109,80 @@ extern "C" int mud_dense(const float* in, int ldi, const float* W, const float* 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_dense, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, ldi, W, bias, out, ldo, B, K, N, act_in, act_out);
   MUD_CHECK_LAUNCH("mud_dense");
+  return MUD_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// A whole small MLP in ONE launch: the z-mapping network (PixelNorm -> dense(nz, 256) -> SiLU -> 3 x [dense(256, 256) -> SiLU],
+// reference ncsnpp_generator_adagn_feat.py:271-277) and the timestep MLP (dense -> SiLU -> dense, :301-305) were chains of
+// 5 and 2 dependent launches of a few microseconds each - at one slice per step the chain's launch boundaries cost more
+// than its arithmetic.  One workgroup per sample, activations ping-pong in LDS, a thread owns an output feature and streams
+// its weight row (the inputs are LDS broadcasts), same multiply-add order along K as k_dense_lane's per-lane sums is NOT kept
+// (one accumulator chain per output here): results agree with the separate launches to fp32 rounding.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mlp_chain(mud_mlp_args a) {
+  extern __shared__ __attribute__((aligned(16))) float msm[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* cur = msm;
+  float* nxt = msm + a.maxdim;
+  const int K0 = a.dims[0];
+  float ssq = 0.f;
+  for (int k = tid; k < K0; k += 256) {
+    const float v = a.x[(int64_t)b * a.ldx + k];
+    cur[k] = v;
+    ssq += v * v;
+  }
+  if (a.pixel_norm) {                                  // x * rsqrt(mean(x^2) + 1e-8)   (PixelNorm, :44-49)
+    __shared__ float red[4];
+    ssq = mud_wave_sum(ssq);
+    if ((tid & 63) == 0) red[tid >> 6] = ssq;
+    __syncthreads();
+    const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K0 + 1e-8f);
+    for (int k = tid; k < K0; k += 256) cur[k] *= inv;
+  }
+  __syncthreads();
+  for (int l = 0; l < a.nlayers; ++l) {
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const bool last = l + 1 == a.nlayers;
+    const float* W = a.W[l];
+    const float* bias = a.b[l];
+    for (int n = tid; n < N; n += 256) {
+      const float* w = W + (int64_t)n * K;
+      float acc = 0.f;
+      int k = 0;
+      if ((K & 3) == 0 && mud_dev_aligned16f(w)) {
+        for (; k < K; k += 4) {
+          const f32x4 wv = *(const f32x4*)(w + k);
+          const f32x4 xv = *(const f32x4*)(cur + k);
+          acc = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], acc))));
+        }
+      }
+      for (; k < K; ++k) acc = fmaf(w[k], cur[k], acc);
+      acc += bias ? bias[n] : 0.f;
+      if (!last || a.act_last) acc = mud_act(acc, a.act);
+      if (last) a.out[(int64_t)b * a.ldo + n] = acc;
+      else nxt[n] = acc;
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+}
+
+extern "C" int mud_mlp_chain(const mud_mlp_args* ap, void* stream) {
+  MUD_REQUIRE(ap, "mud_mlp_chain: null args");
+  mud_mlp_args a = *ap;
+  MUD_REQUIRE(a.x && a.out && a.nlayers >= 1 && a.nlayers <= MUD_MLP_MAX_LAYERS && a.B >= 0, "mud_mlp_chain: bad arguments");
+  int maxdim = 0;
+  for (int l = 0; l <= a.nlayers; ++l) {
+    MUD_REQUIRE(a.dims[l] > 0 && a.dims[l] <= 4096, "mud_mlp_chain: layer width %d out of range", a.dims[l]);
+    if (a.dims[l] > maxdim) maxdim = a.dims[l];
+    if (l < a.nlayers) MUD_REQUIRE(a.W[l] != nullptr, "mud_mlp_chain: null weight matrix");
+  }
+  MUD_REQUIRE(a.ldx >= a.dims[0] && a.ldo >= a.dims[a.nlayers], "mud_mlp_chain: bad row pitches");
+  if (a.B == 0) return MUD_OK;
+  a.maxdim = (maxdim + 3) & ~3;
+  hipLaunchKernelGGL(k_mlp_chain, dim3(a.B), dim3(256), 2 * a.maxdim * sizeof(float), (hipStream_t)stream, a);
+  MUD_CHECK_LAUNCH("mud_mlp_chain");
   return MUD_OK;
 }

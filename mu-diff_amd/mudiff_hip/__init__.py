@@ -47,6 +47,20 @@ class ConvArgs(C.Structure):
     ]
 
 
+MLP_MAX_LAYERS = 6
+
+
+class MlpArgs(C.Structure):
+    """struct mud_mlp_args (include/mudiff_hip.h)."""
+    _fields_ = [
+        ('x', C.c_void_p), ('ldx', C.c_int), ('B', C.c_int),
+        ('nlayers', C.c_int), ('dims', C.c_int * (MLP_MAX_LAYERS + 1)),
+        ('W', C.c_void_p * MLP_MAX_LAYERS), ('b', C.c_void_p * MLP_MAX_LAYERS),
+        ('pixel_norm', C.c_int), ('act', C.c_int), ('act_last', C.c_int),
+        ('out', C.c_void_p), ('ldo', C.c_int), ('maxdim', C.c_int),
+    ]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
     'mud_version': (C.c_int, []),
@@ -56,6 +70,7 @@ _SIGNATURES = {
     'mud_timestep_embedding': (_I, [_P, _P, _I, _I, _F, _P]),
     'mud_pixel_norm': (_I, [_P, _P, _I, _I, _P]),
     'mud_dense': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mud_mlp_chain': (_I, [C.POINTER(MlpArgs), _P]),
     'mud_gn_ws_bytes': (_L, [_I, _L, _I, _I]),
     'mud_gn_scale_shift': (_I, [_P, _I, _L, _I, _I, _I, _F, _P, _P, _L, _P, _P, _I, _P, _P, _P]),
     'mud_gn_scale_shift_from_sums': (_I, [_P, _I, _I, _I, _I, C.c_double, _F, _P, _P, _L, _P, _P, _I, _P]),

@@ -217,6 +217,33 @@ def dense(x, W, bias, act_in=ACT_NONE, act_out=ACT_NONE):
     return out
 
 
+def mlp_chain(x, layers, *, pixel_norm=False, act=ACT_SILU, act_last=False):
+    """x [B,K0] -> [B,N_last] through `layers` = [(W [N,K], bias [N] or None), ...] in ONE launch (activation between the
+    layers, after the last one iff act_last; optional PixelNorm of x first)."""
+    from . import MLP_MAX_LAYERS, MlpArgs
+    require_gpu(x, *[w for w, _ in layers])
+    assert x.dim() == 2 and x.stride(1) == 1 and 1 <= len(layers) <= MLP_MAX_LAYERS
+    a = MlpArgs()
+    xin = x if x.dtype == torch.float32 else x.float()
+    a.x, a.ldx, a.B, a.nlayers = ptr(xin), (xin.stride(0) if xin.shape[0] > 1 else xin.shape[1]), xin.shape[0], len(layers)
+    a.dims[0] = xin.shape[1]
+    keep = [xin]
+    for l, (w, b) in enumerate(layers):
+        w = _f32(w.detach().contiguous())
+        assert w.shape[1] == a.dims[l], (tuple(w.shape), a.dims[l])
+        a.dims[l + 1] = w.shape[0]
+        a.W[l] = w.data_ptr()
+        if b is not None:
+            b = _f32(b.detach().contiguous())
+            a.b[l] = b.data_ptr()
+        keep += [w, b]
+    a.pixel_norm, a.act, a.act_last = int(pixel_norm), act, int(act_last)
+    out = torch.empty(xin.shape[0], a.dims[len(layers)], device=x.device, dtype=torch.float32)
+    a.out, a.ldo = ptr(out), out.shape[1]
+    _launch('mlp_chain', x.device, load().mud_mlp_chain, C.byref(a), STREAM)
+    return out
+
+
 _WS = {}
 
 

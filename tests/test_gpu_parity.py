@@ -92,6 +92,26 @@ def test_embeddings_and_dense():
         assert maxdiff(ops.dense(g(x), g(W), g(b), act_in=ops.ACT_SILU, act_out=ops.ACT_SILU), F.silu(F.linear(F.silu(x), W, b))) < 5e-6
 
 
+@pytest.mark.parametrize('B,dims,pn,act_last', [(3, [100, 256, 256, 256, 256], True, True), (1, [64, 256, 256], False, False), (17, [50, 64, 64], True, True),
+                                                 (2, [37, 19, 5], False, True)])
+def test_mlp_chain_one_launch(B, dims, pn, act_last):
+    """mud_mlp_chain: PixelNorm + the z-mapping MLP (SiLU after every layer) / the timestep MLP (Linear, SiLU, Linear) as ONE launch
+    against torch in fp64 (reference ncsnpp_generator_adagn_feat.py:44-49,271-277,301-305)."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(sum(dims) + B)
+    x = torch.randn(B, dims[0], generator=gen)
+    layers = [(torch.randn(n, k, generator=gen) / math.sqrt(k), torch.randn(n, generator=gen)) for k, n in zip(dims[:-1], dims[1:])]
+    out = ops.mlp_chain(g(x), [(g(w), g(b)) for w, b in layers], pixel_norm=pn, act=ops.ACT_SILU, act_last=act_last)
+    h = x.double()
+    if pn:
+        h = h * torch.rsqrt((h * h).mean(dim=1, keepdim=True) + 1e-8)
+    for l, (w, b) in enumerate(layers):
+        h = h @ w.double().t() + b.double()
+        if l + 1 < len(layers) or act_last:
+            h = F.silu(h)
+    assert out.shape == h.shape and maxdiff(out, h) <= 2e-5 * max(1.0, float(h.abs().max()))
+
+
 @pytest.mark.parametrize('B,H,W,C,G', [(2, 8, 8, 16, 4), (1, 64, 64, 256, 32), (3, 17, 5, 24, 6), (2, 32, 32, 192, 32),
                                        (1, 256, 256, 64, 16), (2, 16, 16, 320, 32)])
 def test_groupnorm_scale_shift(B, H, W, C, G):
