@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
             v *= a.out_scale;
             if (a.act != MUD_ACT_NONE) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
+              for (int e = 0; e < 4; ++e) v[e] = mud_act_fast(v[e], a.act);
             }
             if (a.emul && co4 < emul_lim) v *= *(const f32x4*)(a.emul + opix * a.ld_emul + co4);
             if (a.egate) {
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
           if (valid && cok) {
             float v = acc[m][n][reg] + badd;
             if (a.res) v += a.res[opix * a.ldr + co];
-            v = mud_act(v * a.out_scale, a.act);
+            v = mud_act_fast(v * a.out_scale, a.act);
             if (a.emul && co < emul_lim) v *= a.emul[opix * a.ld_emul + co];
             if (a.egate) {
               const float gt = a.egate[opix * a.ld_egate + co];
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
             v *= a.out_scale;
             if (a.act != MUD_ACT_NONE) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
+              for (int e = 0; e < 4; ++e) v[e] = mud_act_fast(v[e], a.act);
             }
             if (a.emul && co4 < emul_lim) v *= *(const f32x4*)(a.emul + opix * a.ld_emul + co4);
             if (a.egate) {
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
           if (valid && cok) {
             float v = acc[m][n][reg] + badd;
             if (a.res) v += a.res[opix * a.ldr + co];
-            v = mud_act(v * a.out_scale, a.act);
+            v = mud_act_fast(v * a.out_scale, a.act);
             if (a.emul && co < emul_lim) v *= a.emul[opix * a.ld_emul + co];
             if (a.egate) {
               const float gt = a.egate[opix * a.ld_egate + co];
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(mud_conv_args a, const 
       v *= a.out_scale;
       if (a.act != MUD_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = mud_act(v[e], a.act);
+        for (int e = 0; e < 4; ++e) v[e] = mud_act_fast(v[e], a.act);
       }
       *(f32x4*)(a.out + p * a.ldo + co) = v;
       s4 += v;

@@ -59,6 +59,19 @@ __device__ __forceinline__ float mud_act(float v, int act) {
   }
 }
 
+// sigmoid / silu with the hardware exp2 / rcp (each ~1 ulp): for epilogues whose values were produced by split-bf16 MFMAs
+// (2^-17 per product) - the G2 gate convolution evaluates 4e8 sigmoids per batch-16 launch, and expf + a true divide there
+// cost ~25 instructions per element against 5
+__device__ __forceinline__ float mud_act_fast(float v, int act) {
+  switch (act) {
+    case MUD_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+    case MUD_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+    case MUD_ACT_TANH: return tanhf(v);
+    case MUD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    default: return v;
+  }
+}
+
 // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp, ~3e-7 relative overall): used where the value
 // feeds a bf16 hi+lo split (2^-17) or a 16-tap filter, and a full-precision expf + divide would dominate
 __device__ __forceinline__ float mud_fast_silu(float v) {
