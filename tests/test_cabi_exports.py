@@ -64,3 +64,31 @@ def test_host_tables_match_oracle_bitwise():
         for f in ('sigmas', 'a_s', 'a_s_cum', 'sigmas_cum', 'a_s_prev'):
             assert torch.equal(getattr(d, f), getattr(od, f)), f
         assert torch.equal(S.get_time_schedule(cfg, 'cpu'), O.get_time_schedule(cfg))
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The by-value argument structs of the C ABI are mirrored by hand in ctypes (mudiff_hip.ConvArgs / MlpArgs): compile the
+    header with gcc and compare size and every field offset, so a field added on one side only cannot go unnoticed."""
+    import ctypes as C
+    import subprocess
+    import mudiff_hip
+    structs = {'mud_conv_args': mudiff_hip.ConvArgs, 'mud_mlp_args': mudiff_hip.MlpArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "mudiff_hip.h")}"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c11', '-o', str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout
+    seen = 0
+    for ln in out.strip().splitlines():
+        cname, field, val = ln.split()
+        cls = structs[cname]
+        want = C.sizeof(cls) if field == 'size' else getattr(cls, field).offset
+        assert int(val) == want, f'{cname}.{field}: header {val}, ctypes {want}'
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
