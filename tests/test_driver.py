@@ -134,3 +134,28 @@ def test_batched_driver_end_to_end(tmp_path):
     assert float(np.abs(r1 - preds[4:]).max()) > 1e-3
     res = driver.export_and_score(list(preds), list(gts), str(tmp_path / 'png'))
     assert res['count'] == 7 and np.isfinite(res['psnr']) and 0 < res['ssim'] < 1
+
+
+@pytest.mark.gpu
+def test_driver_cli_end_to_end(tmp_path):
+    """`python -m mudiff_hip.driver` as a user runs it (the counterpart of `python engine/test.py ...`, reference engine/test.py:400-491):
+    DDP-prefixed checkpoints found through the fallback directory, .npy volumes, batched sampling, PNG export, metrics in the log."""
+    import subprocess
+    import sys
+    from conftest import PKG, REPO
+    data, out = tmp_path / 'data', tmp_path / 'out'
+    _write_volumes(str(data), n=6, hw=32, seed=5)
+    cfg = O.default_config(**SMALL_CFGS['s32'])
+    os.makedirs(out / 'exp7')
+    for which, name in (('g1', 'gen_diffusive_1'), ('g2', 'gen_diffusive_2')):
+        torch.save({'module.' + k: v for k, v in O.make_state_dict(cfg, which, 1234).items()}, out / 'exp7' / f'{name}.pth')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, PKG, os.environ.get('PYTHONPATH', '')]))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'mudiff_hip.driver', '--input_path', str(data), '--output_path', str(out), '--exp', 'exp7', '--target_modality', 'T2',
+           '--image_size', '32', '--num_channels_dae', '32', '--ch_mult', '1', '2', '4', '--attn_resolutions', '16', '--batch_size', '4']
+    p = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert 'Average PSNR' in p.stderr and 'over 6 slices' in p.stderr
+    pngs = sorted(os.listdir(out / 'generated_samples' / 'pred'))
+    assert pngs == [f'pred_{i:05d}.png' for i in range(6)] and len(os.listdir(out / 'generated_samples' / 'gt')) == 6
