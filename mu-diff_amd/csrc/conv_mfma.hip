@@ -137,7 +137,7 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
 // `x = self.Conv_2(x)`) from the same staged tile - skip_out = skip_w * x + skip_bias - so that x is read from HBM once instead
 // of twice (the skip convs are pure HBM streams: 3.3-4.8 TB/s, 8 % of a forward) at the price of one more tap's MFMAs.
 template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
+__global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
                                                                 unsigned nblocks, int nsplit, int64_t split_stride) {
   using G = CmGeo<KS, MT, WM, WN, DUAL>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_mfma(mud_conv_args a, 
   const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
-  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || WM * WN >= 8) && a.res && vec && !a.sub2;      // (DUAL has no residual)
+  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2;      // (DUAL has no residual)
   f32x4 rpre[2][MT][4];
   const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
   auto prefetch_res = [&]() {
@@ -1211,7 +1211,7 @@ static int cm_launch(const mud_conv_args& a, hipStream_t s) {
 // 3x3 tile variant by problem size: big tiles (more MFMA work per weight byte) once they still fill the 256 CUs.
 // Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
 // beats MT=4 (one workgroup per CU) by 15-40 % on every layer shape; MT=1 only when MT=2 cannot give 2 blocks/CU.
-enum { CMV_8X2, CMV_16X1, CMV_MT2, CMV_MT1 };
+enum { CMV_8X2, CMV_16X1, CMV_MT2, CMV_MT1, CMV_8X1R };
 static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
   const int64_t ntiles = mud_cdiv(a.Cout, CM_BN);
   int64_t nb;
@@ -1225,7 +1225,13 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
   const int64_t blocks16 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 16) * ntiles * a.B;
   const int64_t blocks2 = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 8) * ntiles * a.B;
   static const bool no16 = getenv("MUD_CONV_NO16") != nullptr;   // A/B knob
-  if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
+  // 64 -> 64 layers (four K chunks: a quarter of a workgroup's life is first fetch + epilogue): 8 waves x ONE row x 64 channels,
+  // 79 KiB of LDS and 110 VGPRs, so two workgroups share a CU (four waves per SIMD) and one's residual / store phase runs
+  // under the other's K loop.  Measured against the 16-row tile (profiles/r02_j_ab_8x1row.txt): with a residual 330 -> 305 us,
+  // without 307 -> 303 us; deeper reductions (128 / 192 / 256 -> 64) are equal, so they keep the tile with less halo.
+  static const bool no8x1r = getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob
+  if (!no8x1r && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
+  else if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
   else if (!no16 && a.H >= 16 && blocks16 >= 256) v = CMV_16X1, nb = blocks16;
   else if (blocks2 >= 512 && a.H >= 8) v = CMV_MT2, nb = blocks2;
   else v = CMV_MT1, nb = mud_cdiv(a.W, 32) * mud_cdiv(a.H, 4) * ntiles * a.B;
@@ -1301,6 +1307,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
       case CMV_8X2: return cm_launch<3, 2, 4, 2>(a, s);
       case CMV_16X1: return cm_launch<3, 2, 8, 1>(a, s);
       case CMV_MT2: return cm_launch<3, 2>(a, s);
+      case CMV_8X1R: return cm_launch<3, 1, 8, 1>(a, s);
       default: return cm_launch<3, 1>(a, s);
     }
   }
