@@ -318,9 +318,20 @@ FOLD_GN = os.environ.get('MUD_FOLD_GN', '1') != '0'      # A/B knob: 0 = one gn_
 FUSE_SKIP = os.environ.get('MUD_FUSE_SKIP', '1') != '0'     # A/B knob: 0 = the 1x1 skip conv stays its own launch (round-1 behaviour)
 
 
+def conv3x3_would_split_k(x: View, cout):
+    """Would mud_conv2d_mfma deal the K chunks of this 3x3 launch to several workgroups (small grid, long reduction)?"""
+    a = ConvArgs()
+    a.x, a.B, a.H, a.W, a.Cin, a.ldx, a.ks, a.stride, a.pad = x.ptr, x.B, x.H, x.W, x.C, x.ld, 3, 1, 1
+    a.out, a.Cout, a.ldo = x.ptr, cout, (cout + 3) & ~3          # (only sizes and alignment are looked at)
+    return load().mud_conv2d_mfma_splitk_bytes(C.byref(a)) > 0
+
+
 def fused_skip_ok(x: View, cout, pro_mode):
-    """Can mud_conv2d_mfma produce the block's 1x1 skip conv alongside its 3x3 conv (mud_conv_args.skip_*)?"""
-    return FUSE_SKIP and pro_mode == PRO_AFFINE_SILU and x.C % 4 == 0 and 8 <= x.C <= 512 and cout % 4 == 0
+    """Should mud_conv2d_mfma produce the block's 1x1 skip conv alongside its 3x3 conv (mud_conv_args.skip_*)?  Not where the
+    3x3 launch would otherwise be split over K (one slice at a time, 64x64 maps): the fused kernel cannot split, and a serial
+    32-chunk reduction on 128 workgroups costs more than the second read of x saves (512->256: 109 us fused vs 59 + 23 us)."""
+    return (FUSE_SKIP and pro_mode == PRO_AFFINE_SILU and x.C % 4 == 0 and 8 <= x.C <= 512 and cout % 4 == 0
+            and not conv3x3_would_split_k(x, cout))
 
 
 def resolve_pro(pro):

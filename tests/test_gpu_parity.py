@@ -283,7 +283,7 @@ def test_conv_with_fused_skip_conv(B, H, W, Cin, Cout):
     bias, bias_s, b2 = torch.randn(Cout, generator=gen), torch.randn(Cout, generator=gen), torch.randn(B, Cout, generator=gen)
     sc, sh = torch.rand(B, Cin, generator=gen) + 0.5, torch.randn(B, Cin, generator=gen)
     xv, wp, w2p = ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ops.pack_conv_weight(g(w2))
-    assert ops.fused_skip_ok(xv, Cout, ops.PRO_AFFINE_SILU)
+    assert ops.fused_skip_ok(xv, Cout, ops.PRO_AFFINE_SILU) == (not ops.conv3x3_would_split_k(xv, Cout))      # (the model fuses only where the launch would not be split over K)
     arena = ops.StatsArena(torch.device(DEV))
     out, skip = ops.View.empty(B, H, W, Cout, DEV, arena), ops.View.empty(B, H, W, Cout + 8, DEV).slice(4, Cout)
     pro = (g(sc), g(sh), ops.PRO_AFFINE_SILU)
