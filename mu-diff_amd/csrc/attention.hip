@@ -518,16 +518,21 @@ __global__ __launch_bounds__(256) void k_attention_combine(const float* __restri
   *(f32x4*)(out + ((int64_t)b * N + q) * ldo + c) = acc * (1.0f / l);
 }
 
-// Key splits used for (B, N): 1 unless the (batch x 128-query block) grid leaves most of the 256 CUs idle.
+// Key splits used for (B, N).  A workgroup owns 128 queries and the whole key range; the chip runs 256 workgroups at a time (one
+// per CU), so the launch takes ceil(wgs / 256) rounds of full-length workgroups.  Splitting the keys ns ways gives ns times the
+// workgroups of 1/ns the length (+ a small merge): chosen to minimise rounds / ns, e.g. 128 workgroups (4 slices of 64x64):
+// 1 round -> 2 splits, half the time; 384 (12 slices): 2 rounds -> 2 splits, 3 rounds of half length; 512: no split.
 static int at_splits(int B, int N) {
   const int64_t wgs = (int64_t)B * mud_cdiv(N, 128);
   const int ntiles = (int)mud_cdiv(N, 32);
-  if (wgs >= 128 || ntiles < 8) return 1;
-  int ns = (int)mud_cdiv(256, wgs);
-  if (ns > 16) ns = 16;
-  if (ns > ntiles / 4) ns = ntiles / 4;               // at least 4 key tiles (128 keys) per split
-  if (ns < 1) ns = 1;
-  const int tps = (int)mud_cdiv(ntiles, ns);
+  if (ntiles < 8) return 1;
+  int best = 1;
+  double best_cost = (double)mud_cdiv(wgs, 256);
+  for (int ns = 2; ns <= 16 && ns <= ntiles / 4; ++ns) {        // at least 4 key tiles (128 keys) per split
+    const double cost = (double)mud_cdiv(wgs * ns, 256) / ns + 0.01 * ns;      // + merge pass and partial traffic
+    if (cost < best_cost - 1e-9) best_cost = cost, best = ns;
+  }
+  const int tps = (int)mud_cdiv(ntiles, best);
   return (int)mud_cdiv(ntiles, tps);                  // no empty split
 }
 
