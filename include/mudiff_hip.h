@@ -82,6 +82,9 @@ typedef struct mud_mlp_args {
   int maxdim;                                    /* filled in by the library */
 } mud_mlp_args;
 int mud_mlp_chain(const mud_mlp_args* a, void* stream);
+/* n (<= 4) independent chains a[0..n) in one launch (the z-mapping network and the timestep MLP of a generator do not depend on  */
+/* each other).                                                                                                                 */
+int mud_mlp_chains(const mud_mlp_args* a, int n, void* stream);
 
 /* ---- GroupNorm statistics -> per-(sample, channel) scale/shift for a consumer's prologue
  *      (torch native_group_norm as used by backbones/layerspp.py:37-65,103, eps 1e-6, biased var).
@@ -141,6 +144,10 @@ typedef struct mud_conv_args {
   /* time), the K chunks of a tile are dealt to several workgroups that write raw partial tiles here, and a second small     */
   /* launch adds them in a fixed order and applies the epilogue.  mud_conv2d_mfma_splitk_bytes() sizes it; NULL = never split. */
   void* splitk_ws; int64_t splitk_ws_bytes;
+  /* optional arrival counters (splitk_ncounters of them, ZERO when handed over; every launch leaves them zero): with them the   */
+  /* last workgroup to finish an output tile adds the slabs (same fixed order) and applies the epilogue, so a split convolution   */
+  /* is one launch instead of two.  One array per stream: launches that may run concurrently must not share it.                   */
+  unsigned* splitk_counters; int splitk_ncounters;
   /* mud_conv2d_mfma, ks 3, pro_mode AFFINE_SILU, plain epilogue - the residual block's 1x1 skip convolution of the RAW input     */
   /* (layerspp.py:320-321, x = Conv_2(x)) produced by the same launch: skip_out[pixel, co] = sum_ci x[pixel, ci] * skip_w + bias. */
   /* skip_w: mud_pack_weights(ks = 1) of the [Cout, Cin] matrix; x is then read from HBM once instead of twice.  Cin <= 512.      */

@@ -253,17 +253,18 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
 
     def _embeddings(self, time_cond, z):
         mods = self.all_modules
-        # PixelNorm + the whole z-mapping MLP in one launch (SiLU after every layer, reference :271-277)
-        zemb = ops.mlp_chain(z, [(m.weight, m.bias) for m in self.z_transform if isinstance(m, nn.Linear)], pixel_norm=True,
-                             act=ACT_SILU, act_last=True)
+        # PixelNorm + the whole z-mapping MLP (SiLU after every layer, reference :271-277) and the timestep MLP (Linear, SiLU, Linear,
+        # :301-305) do not depend on each other: both chains side by side in one launch
+        zchain = dict(x=z, layers=[(m.weight, m.bias) for m in self.z_transform if isinstance(m, nn.Linear)], pixel_norm=True,
+                      act=ACT_SILU, act_last=True)
         if self.embedding_type == 'fourier':      # Gaussian Fourier features of log(sigma) (reference :286-290)
             temb = mods[self._plan[0]['idx']].run_log(time_cond)
         else:
             temb = layers.get_timestep_embedding(time_cond, self.nf)
         if not self.conditional:
-            return None, zemb
+            return None, ops.mlp_chains([zchain])[0]
         l0, l1 = (mods[e['idx']] for e in self._plan if e['kind'] == 'temb')
-        temb = ops.mlp_chain(temb, [(l0.weight, l0.bias), (l1.weight, l1.bias)], act=ACT_SILU, act_last=False)     # Linear, SiLU, Linear (:301-305)
+        zemb, temb = ops.mlp_chains([zchain, dict(x=temb, layers=[(l0.weight, l0.bias), (l1.weight, l1.bias)], act=ACT_SILU, act_last=False)])
         return temb, zemb
 
     def _check_inputs(self, x, conds, pseudo=None):

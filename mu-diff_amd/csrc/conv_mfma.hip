@@ -136,9 +136,16 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
 // DUAL: the launch also produces the residual block's 1x1 skip convolution of the RAW input (reference layerspp.py:320-321,
 // `x = self.Conv_2(x)`) from the same staged tile - skip_out = skip_w * x + skip_bias - so that x is read from HBM once instead
 // of twice (the skip convs are pure HBM streams: 3.3-4.8 TB/s, 8 % of a forward) at the price of one more tap's MFMAs.
+// split-K reduced inside the launch (`a` is then the REAL convolution): slab workspace + per-output-tile arrival counters.
+// counters == NULL with nsplit > 1: `a` describes raw NHWC partial slabs and k_splitk_epilogue reduces them (second launch).
+struct CmFin {
+  float* ws;
+  unsigned* counters;
+};
+
 template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
-                                                                unsigned nblocks, int nsplit, int64_t split_stride) {
+                                                                unsigned nblocks, int nsplit, int64_t split_stride, CmFin fin) {
   using G = CmGeo<KS, MT, WM, WN, DUAL>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -349,7 +356,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
-  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2;      // (DUAL has no residual)
+  const bool slab_mode = KS == 3 && !DUAL && nsplit > 1 && fin.counters != nullptr;    // block-uniform
+  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2 && !slab_mode;      // (DUAL has no residual)
   f32x4 rpre[2][MT][4];
   const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
   auto prefetch_res = [&]() {
@@ -511,6 +519,56 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
 #endif
       if (G::NG == 1 && more) store_a(kc + 1, nxt);
       __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
+    }
+  }
+
+  if constexpr (KS == 3 && !DUAL) {
+    if (slab_mode) {
+      // ---- split-K, reduced in this launch.  Every workgroup dumps its accumulators to its slab in REGISTER order (word j of thread
+      // t at [j * threads + t]: full coalesced lines, no transposition); the LAST workgroup to arrive for an output tile (arrival
+      // counter, which it leaves at zero for the next launch) adds the nsplit slabs in slab order - the result does not depend on who
+      // is last - and alone runs the epilogue below.
+      // Visibility across the XCDs' private L2s WITHOUT device-scope fences (a release fence is a whole-L2 write-back, an acquire a
+      // whole-L2 invalidate: measured +80 us per launch): the slab words are agent-scope relaxed atomics - write-through stores,
+      // loads that do not hit stale lines - each wave drains its stores before the barrier, and only then is the arrival counted.
+      constexpr int NT = 64 * WM * WN;
+      const unsigned nslots = nblocks / (unsigned)nsplit;
+      const unsigned slot = ((unsigned)b * (unsigned)tiles_per_img + (unsigned)tile) * (unsigned)ntiles + (unsigned)nt;
+      const int64_t tile_words = (int64_t)NT * 32 * MT;
+      float* mine = fin.ws + ((int64_t)ksi * nslots + slot) * tile_words + tid;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            __hip_atomic_store(mine + ((m * 2 + n) * 16 + reg) * NT, acc[m][n][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = (int*)smem;                     // the staging buffers are dead
+      if (tid == 0) {
+        unsigned* cnt = fin.counters + slot;
+        const int last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsplit - 1u;
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+      }
+      __syncthreads();
+      if (!*flag) return;
+      __syncthreads();                            // (the epilogue reuses the flag's LDS word)
+      const float* slab0 = fin.ws + (int64_t)slot * tile_words + tid;
+      for (int k = 0; k < nsplit; ++k) {
+        const float* src = slab0 + (int64_t)k * nslots * tile_words;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const float pv = __hip_atomic_load(src + ((m * 2 + n) * 16 + reg) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              acc[m][n][reg] = k == 0 ? pv : acc[m][n][reg] + pv;
+            }
+      }
     }
   }
 
@@ -1119,19 +1177,26 @@ static bool cm_split_eligible(const mud_conv_args& a) {
          (!a.bias2 || (mud_aligned16(a.bias2) && a.bias2_ld % 4 == 0));
 }
 
+// bytes of nsplit slabs of whole output tiles (>= the NHWC slabs of the two-launch path, which cover only real pixels / channels)
+static int64_t cm_slab_bytes(int ns, int64_t blocks, int tile_words) { return (int64_t)ns * blocks * tile_words * 4; }
+
 // how many K slices a 3x3 launch of `blocks` workgroups over `nchunks` 16-channel chunks is cut into (1 = no split)
 static int cm_splits(int64_t blocks, int nchunks) {
   static const int force = getenv("MUD_CONV_SPLITK") ? atoi(getenv("MUD_CONV_SPLITK")) : -1;   // A/B knob: 0/1 = never, n = force n
+  static const int kMaxBlocks = getenv("MUD_SPLITK_MAXBLOCKS") ? atoi(getenv("MUD_SPLITK_MAXBLOCKS")) : 192;   // tuning knobs
+  static const int kTarget = getenv("MUD_SPLITK_TARGET") ? atoi(getenv("MUD_SPLITK_TARGET")) : 512;
+  static const int kMinChunks = getenv("MUD_SPLITK_MINCHUNKS") ? atoi(getenv("MUD_SPLITK_MINCHUNKS")) : 16;
+  static const int kMinPer = getenv("MUD_SPLITK_MINPER") ? atoi(getenv("MUD_SPLITK_MINPER")) : 4;
   int ns = 1;
   if (force >= 0) ns = force < 1 ? 1 : force;
-  else if (blocks <= 192 && nchunks >= 16) {
+  else if (blocks <= kMaxBlocks && nchunks >= kMinChunks) {
     // measured at one slice (profiles/r02_layer_times_b1_*.txt): 64x64 maps with >= 256 input channels gain (256->256: 50 -> 43 us,
     // 512->256: 89 -> 59 us, 384->256: 70 -> 51 us); 128x128 / 256x256 maps and shorter reductions lose (every workgroup pays
     // ~8 us of first-fetch + epilogue latency, and the second launch ~8 us), so they are left alone
-    ns = (int)((512 + blocks - 1) / blocks);
+    ns = (int)((kTarget + blocks - 1) / blocks);
     if (ns > 4) ns = 4;
   }
-  if (ns > nchunks / 4) ns = nchunks / 4;             // at least 4 chunks per slice: the prologue / epilogue must stay amortised
+  if (ns > nchunks / kMinPer) ns = nchunks / kMinPer;             // at least 4 chunks per slice: the prologue / epilogue must stay amortised
   if (ns < 1) ns = 1;
   while (ns > 1 && (nchunks + ns - 1) / ns * (ns - 1) >= nchunks) --ns;   // every slice gets at least one chunk
   return ns;
@@ -1168,7 +1233,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
     const int64_t npix = (int64_t)a.B * a.H * a.W;
     int ns = 1;
     if (!DUAL && a.splitk_ws && mud_aligned16(a.splitk_ws) && cm_split_eligible(a)) ns = cm_splits(nblocks, k16s);
-    if (ns > 1 && a.splitk_ws_bytes < (int64_t)ns * npix * a.Cout * 4) ns = 1;      // workspace too small: run unsplit
+    if (ns > 1 && a.splitk_ws_bytes < cm_slab_bytes(ns, nblocks, 64 * WM * WN * 32 * MT)) ns = 1;      // workspace too small: run unsplit
     if (ns > 1) {
       mud_conv_args p = a;                       // raw partial sums: no epilogue terms, output = slab ksi of the workspace
       p.out = (float*)a.splitk_ws;
@@ -1178,8 +1243,16 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       p.act = MUD_ACT_NONE;
       p.stats = nullptr;
       const int64_t stride = npix * a.Cout;
+      // with arrival counters (one per output tile, zero between launches) the last workgroup of each tile reduces the slabs itself
+      static const bool two_launches = getenv("MUD_CONV_SPLITK_2LAUNCH") != nullptr;   // A/B knob
+      if (!two_launches && a.splitk_counters && nblocks <= a.splitk_ncounters) {
+        hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, a, tiles_x,
+                           (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, (int64_t)0, CmFin{(float*)a.splitk_ws, a.splitk_counters});
+        MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K, reduced in the launch)");
+        return MUD_OK;
+      }
       hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, p, tiles_x,
-                         (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, stride);
+                         (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, stride, CmFin{nullptr, nullptr});
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K)");
       const int64_t HW = (int64_t)a.H * a.W;
       int ppb = 32;                              // pixels per block of the reduce: a divisor of H*W (one sample per block)
@@ -1190,7 +1263,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       return MUD_OK;
     }
     hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)nblocks), dim3(64 * WM * WN), lds, s, a, tiles_x, (int)tiles,
-                       ntiles, k16s, (unsigned)nblocks, 1, (int64_t)0);
+                       ntiles, k16s, (unsigned)nblocks, 1, (int64_t)0, CmFin{nullptr, nullptr});
   } else
     hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), lds, s, a, tiles_x, (int)tiles, ntiles, k16s,
                        (unsigned)nblocks);
@@ -1242,9 +1315,10 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
 extern "C" int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* ap) {
   if (!ap || ap->ks != 3 || ap->B <= 0 || ap->H <= 0 || ap->W <= 0 || ap->Cin <= 0 || ap->Cout <= 0 || !cm_split_eligible(*ap)) return 0;
   int64_t blocks = 0;
-  cm_variant3(*ap, &blocks);
+  const int v = cm_variant3(*ap, &blocks);
   const int ns = cm_splits(blocks, (int)mud_cdiv(ap->Cin, 16));
-  return ns > 1 ? (int64_t)ns * ap->B * ap->H * ap->W * ap->Cout * 4 : 0;
+  const int tile_words = (v == CMV_8X2 || v == CMV_16X1) ? 512 * 64 : v == CMV_MT2 ? 256 * 64 : v == CMV_8X1R ? 512 * 32 : 256 * 32;   // threads x accumulators
+  return ns > 1 ? cm_slab_bytes(ns, blocks, tile_words) : 0;
 }
 
 extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {

@@ -121,9 +121,15 @@ extern "C" int mud_dense(const float* in, int ldi, const float* W, const float* 
 // its weight row (the inputs are LDS broadcasts), same multiply-add order along K as k_dense_lane's per-lane sums is NOT kept
 // (one accumulator chain per output here): results agree with the separate launches to fp32 rounding.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mlp_chain(mud_mlp_args a) {
+#define MUD_MLP_MAX_CHAINS 4
+struct MlpPack {
+  mud_mlp_args c[MUD_MLP_MAX_CHAINS];
+};
+__global__ __launch_bounds__(256) void k_mlp_chain(MlpPack pack) {
   extern __shared__ __attribute__((aligned(16))) float msm[];
+  const mud_mlp_args& a = pack.c[blockIdx.y];     // independent chains side by side (blockIdx.y), one workgroup per sample
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;                           // block-uniform
   float* cur = msm;
   float* nxt = msm + a.maxdim;
   const int K0 = a.dims[0];
@@ -169,9 +175,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain(mud_mlp_args a) {
   }
 }
 
-extern "C" int mud_mlp_chain(const mud_mlp_args* ap, void* stream) {
-  MUD_REQUIRE(ap, "mud_mlp_chain: null args");
-  mud_mlp_args a = *ap;
+static int mlp_check(mud_mlp_args& a) {
   MUD_REQUIRE(a.x && a.out && a.nlayers >= 1 && a.nlayers <= MUD_MLP_MAX_LAYERS && a.B >= 0, "mud_mlp_chain: bad arguments");
   int maxdim = 0;
   for (int l = 0; l <= a.nlayers; ++l) {
@@ -180,9 +184,29 @@ extern "C" int mud_mlp_chain(const mud_mlp_args* ap, void* stream) {
     if (l < a.nlayers) MUD_REQUIRE(a.W[l] != nullptr, "mud_mlp_chain: null weight matrix");
   }
   MUD_REQUIRE(a.ldx >= a.dims[0] && a.ldo >= a.dims[a.nlayers], "mud_mlp_chain: bad row pitches");
-  if (a.B == 0) return MUD_OK;
   a.maxdim = (maxdim + 3) & ~3;
-  hipLaunchKernelGGL(k_mlp_chain, dim3(a.B), dim3(256), 2 * a.maxdim * sizeof(float), (hipStream_t)stream, a);
+  return MUD_OK;
+}
+
+extern "C" int mud_mlp_chains(const mud_mlp_args* ap, int n, void* stream) {
+  MUD_REQUIRE(ap && n >= 1 && n <= MUD_MLP_MAX_CHAINS, "mud_mlp_chains: 1..%d chains per launch", MUD_MLP_MAX_CHAINS);
+  MlpPack pack;
+  int maxB = 0, maxdim = 0;
+  for (int i = 0; i < n; ++i) {
+    pack.c[i] = ap[i];
+    const int rc = mlp_check(pack.c[i]);
+    if (rc != MUD_OK) return rc;
+    if (pack.c[i].B > maxB) maxB = pack.c[i].B;
+    if (pack.c[i].maxdim > maxdim) maxdim = pack.c[i].maxdim;
+  }
+  for (int i = n; i < MUD_MLP_MAX_CHAINS; ++i) pack.c[i] = pack.c[0];
+  if (maxB == 0) return MUD_OK;
+  hipLaunchKernelGGL(k_mlp_chain, dim3(maxB, n), dim3(256), 2 * maxdim * sizeof(float), (hipStream_t)stream, pack);
   MUD_CHECK_LAUNCH("mud_mlp_chain");
   return MUD_OK;
+}
+
+extern "C" int mud_mlp_chain(const mud_mlp_args* ap, void* stream) {
+  MUD_REQUIRE(ap, "mud_mlp_chain: null args");
+  return mud_mlp_chains(ap, 1, stream);
 }

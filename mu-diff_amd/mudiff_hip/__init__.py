@@ -43,6 +43,7 @@ class ConvArgs(C.Structure):
         ('gn_sums', C.c_void_p), ('gn_sums_ld', C.c_int), ('gn_G', C.c_int), ('gn_eps', C.c_float), ('gn_count', C.c_double),
         ('gn_gamma', C.c_void_p), ('gn_beta', C.c_void_p), ('gn_bstride', C.c_int64),
         ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
+        ('splitk_counters', C.c_void_p), ('splitk_ncounters', C.c_int),
         ('skip_w', C.c_void_p), ('skip_bias', C.c_void_p), ('skip_out', C.c_void_p), ('skip_ldo', C.c_int),
     ]
 
@@ -71,6 +72,7 @@ _SIGNATURES = {
     'mud_pixel_norm': (_I, [_P, _P, _I, _I, _P]),
     'mud_dense': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mud_mlp_chain': (_I, [C.POINTER(MlpArgs), _P]),
+    'mud_mlp_chains': (_I, [C.POINTER(MlpArgs), _I, _P]),
     'mud_gn_ws_bytes': (_L, [_I, _L, _I, _I]),
     'mud_gn_scale_shift': (_I, [_P, _I, _L, _I, _I, _I, _F, _P, _P, _L, _P, _P, _I, _P, _P, _P]),
     'mud_gn_scale_shift_from_sums': (_I, [_P, _I, _I, _I, _I, C.c_double, _F, _P, _P, _L, _P, _P, _I, _P]),

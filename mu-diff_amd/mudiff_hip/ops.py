@@ -217,13 +217,10 @@ def dense(x, W, bias, act_in=ACT_NONE, act_out=ACT_NONE):
     return out
 
 
-def mlp_chain(x, layers, *, pixel_norm=False, act=ACT_SILU, act_last=False):
-    """x [B,K0] -> [B,N_last] through `layers` = [(W [N,K], bias [N] or None), ...] in ONE launch (activation between the
-    layers, after the last one iff act_last; optional PixelNorm of x first)."""
-    from . import MLP_MAX_LAYERS, MlpArgs
+def _mlp_args(a, x, layers, pixel_norm, act, act_last):
+    from . import MLP_MAX_LAYERS
     require_gpu(x, *[w for w, _ in layers])
     assert x.dim() == 2 and x.stride(1) == 1 and 1 <= len(layers) <= MLP_MAX_LAYERS
-    a = MlpArgs()
     xin = x if x.dtype == torch.float32 else x.float()
     a.x, a.ldx, a.B, a.nlayers = ptr(xin), (xin.stride(0) if xin.shape[0] > 1 else xin.shape[1]), xin.shape[0], len(layers)
     a.dims[0] = xin.shape[1]
@@ -240,8 +237,28 @@ def mlp_chain(x, layers, *, pixel_norm=False, act=ACT_SILU, act_last=False):
     a.pixel_norm, a.act, a.act_last = int(pixel_norm), act, int(act_last)
     out = torch.empty(xin.shape[0], a.dims[len(layers)], device=x.device, dtype=torch.float32)
     a.out, a.ldo = ptr(out), out.shape[1]
-    _launch('mlp_chain', x.device, load().mud_mlp_chain, C.byref(a), STREAM)
-    return out
+    return out, keep
+
+
+def mlp_chain(x, layers, *, pixel_norm=False, act=ACT_SILU, act_last=False):
+    """x [B,K0] -> [B,N_last] through `layers` = [(W [N,K], bias [N] or None), ...] in ONE launch (activation between the
+    layers, after the last one iff act_last; optional PixelNorm of x first)."""
+    return mlp_chains([dict(x=x, layers=layers, pixel_norm=pixel_norm, act=act, act_last=act_last)])[0]
+
+
+def mlp_chains(chains):
+    """Up to four independent chains (dicts of mlp_chain's arguments) side by side in ONE launch -> list of outputs."""
+    from . import MlpArgs
+    assert 1 <= len(chains) <= 4
+    arr = (MlpArgs * len(chains))()
+    outs, keep = [], []
+    for a, c in zip(arr, chains):
+        o, k = _mlp_args(a, c['x'], c['layers'], c.get('pixel_norm', False), c.get('act', ACT_SILU), c.get('act_last', False))
+        outs.append(o)
+        keep.append(k)
+    require_gpu(*[c['x'] for c in chains])
+    _launch('mlp_chain', chains[0]['x'].device, load().mud_mlp_chains, arr, len(chains), STREAM)
+    return outs
 
 
 _WS = {}
@@ -316,6 +333,19 @@ FOLD_GN = os.environ.get('MUD_FOLD_GN', '1') != '0'      # A/B knob: 0 = one gn_
 
 
 FUSE_SKIP = os.environ.get('MUD_FUSE_SKIP', '1') != '0'     # A/B knob: 0 = the 1x1 skip conv stays its own launch (round-1 behaviour)
+
+
+_SPLITK_COUNTERS = {}
+
+
+def splitk_counters(device):
+    """Arrival counters of the in-launch split-K reduction (mud_conv_args.splitk_counters): one zeroed array per (device, stream) -
+    launches on one stream are ordered, and every launch leaves the counters at zero."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _SPLITK_COUNTERS.get(key)
+    if buf is None:
+        buf = _SPLITK_COUNTERS[key] = torch.zeros(4096, device=device, dtype=torch.int32)
+    return buf
 
 
 def conv3x3_would_split_k(x: View, cout):
@@ -450,6 +480,8 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
         if nws > 0:
             keep = (keep, torch.empty(nws, device=x.device, dtype=torch.uint8))
             a.splitk_ws, a.splitk_ws_bytes = ptr(keep[1]), nws
+            cnt = splitk_counters(x.device)
+            a.splitk_counters, a.splitk_ncounters = ptr(cnt), cnt.numel()
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks + skip_flops     # algorithmic (sub2 issues 4x this)

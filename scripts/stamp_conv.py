@@ -19,6 +19,12 @@ for H, Cin, Cout, res in [(256, 64, 64, True), (256, 64, 64, False), (128, 128, 
     for _ in range(3):
         ops.conv(x, w, 3, Cout, mfma=True, pro=(sc, sh, ops.PRO_AFFINE_SILU), res=r, out=out)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.conv(x, w, 3, Cout, mfma=True, pro=(sc, sh, ops.PRO_AFFINE_SILU), res=r, out=out)
+    e1.record(); torch.cuda.synchronize()
+    print(f'   back-to-back launches: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per conv (incl. split-K epilogue if any)')
     buf = np.zeros(64 * 64, dtype=np.uint64)
     assert lib.mud_debug_read_stamps(buf.ctypes.data) == 0
     st = buf.reshape(64, 64).astype(np.int64)

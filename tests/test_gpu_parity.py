@@ -112,6 +112,24 @@ def test_mlp_chain_one_launch(B, dims, pn, act_last):
     assert out.shape == h.shape and maxdiff(out, h) <= 2e-5 * max(1.0, float(h.abs().max()))
 
 
+def test_mlp_chains_side_by_side():
+    """mud_mlp_chains: independent chains (different widths, depths, batch sizes) in one launch give exactly what the separate
+    launches give (a generator's z-mapping network and timestep MLP run this way)."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(11)
+    specs = [(3, [100, 256, 256, 256, 256], True, True), (3, [128, 512, 512], False, False), (1, [37, 19, 5], False, True), (5, [64, 64], True, False)]
+    chains = []
+    for B, dims, pn, al in specs:
+        layers = [(g(torch.randn(n, k, generator=gen) / math.sqrt(k)), g(torch.randn(n, generator=gen))) for k, n in zip(dims[:-1], dims[1:])]
+        chains.append(dict(x=g(torch.randn(B, dims[0], generator=gen)), layers=layers, pixel_norm=pn, act=ops.ACT_SILU, act_last=al))
+    for n in (2, 4):
+        outs = ops.mlp_chains(chains[:n])
+        for c, o in zip(chains[:n], outs):
+            assert torch.equal(o, ops.mlp_chain(c['x'], c['layers'], pixel_norm=c['pixel_norm'], act=c['act'], act_last=c['act_last']))
+    with pytest.raises(AssertionError):
+        ops.mlp_chains(chains + chains[:1])
+
+
 @pytest.mark.parametrize('B,H,W,C,G', [(2, 8, 8, 16, 4), (1, 64, 64, 256, 32), (3, 17, 5, 24, 6), (2, 32, 32, 192, 32),
                                        (1, 256, 256, 64, 16), (2, 16, 16, 320, 32)])
 def test_groupnorm_scale_shift(B, H, W, C, G):
@@ -345,6 +363,20 @@ def test_conv_split_k_small_grids(B, H, W, Cin, Cout):
         assert mudiff_hip.load().mud_conv2d_mfma(C_.byref(a), mudiff_hip.stream_ptr()) == 0
         torch.cuda.synchronize()
         assert maxdiff(out2.to_nchw(), y) <= 2e-5
+        # the wrapper's launch reduced the slabs itself (arrival counters, one launch); the same problem with a workspace but WITHOUT
+        # counters takes the two-launch path - same slabs, same order, same epilogue arithmetic: bit-identical outputs
+        cnt = ops.splitk_counters(torch.device(DEV))
+        assert int(cnt.abs().sum()) == 0                                # every launch leaves the counters at zero
+        out3, ws = ops.View.empty(B, H, W, Cout, DEV), torch.empty(nws, device=DEV, dtype=torch.uint8)
+        a.out, a.splitk_ws, a.splitk_ws_bytes = out3.ptr, C_.c_void_p(ws.data_ptr()), nws
+        assert mudiff_hip.load().mud_conv2d_mfma(C_.byref(a), mudiff_hip.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out3.to_nchw().cpu(), y)
+        out4 = ops.View.empty(B, H, W, Cout, DEV)
+        for _ in range(3):                                              # whichever workgroup arrives last, the sum is the same
+            ops.conv(xv, wp, 3, Cout, out=out4, **kw)
+            assert torch.equal(out4.to_nchw().cpu(), y)
+        assert int(cnt.abs().sum()) == 0
 
 
 def test_fir_against_reference_golden():
