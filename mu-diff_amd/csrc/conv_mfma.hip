@@ -37,6 +37,9 @@
 #ifndef CM_PRIO
 #define CM_PRIO 0
 #endif
+#ifndef CM_ORDER
+#define CM_ORDER 2      // MFMA issue order inside a k16 step: 2 = the two accumulators alternate (same per-accumulator order as 0: bit-identical)
+#endif
 #ifndef CM_FAKE16
 #define CM_FAKE16 0
 #endif
@@ -476,6 +479,22 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             const bf16x8 ah = *(const bf16x8*)(cur + lane_a + off);
             const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
 #endif
+#if CM_ORDER == 1      // A/B knob: consecutive MFMAs share an operand register (ah x4, then al x2; B pairs shared)
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[m][1], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
+#elif CM_ORDER == 2    // term by term, the two accumulators alternate: no back-to-back MFMAs on one accumulator (64->64 layers -2 %,
+                       // others +-0: profiles/r02_l_ab_mfma_order.txt); each accumulator still adds its terms in the order lo.hi, hi.lo, hi.hi
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
+#else
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
 #if CM_FAKE16
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
 #endif
             }
+#endif
           }
         }
         // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),

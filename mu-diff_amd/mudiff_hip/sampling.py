@@ -199,12 +199,14 @@ class GraphSampler:
         for g_ in gens:
             g_.begin_loop_cache()
         try:
+            # capture_error_mode 'thread_local': only THIS thread's calls are policed during capture - a process-group watchdog
+            # thread (RCCL) polling its events next to us must not invalidate the capture
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph):
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._step()
             self._first_out = (self.x01, self.x02, self.x_new)
             self.graph_rest = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph_rest, pool=self.graph.pool()):
+            with torch.no_grad(), torch.cuda.graph(self.graph_rest, pool=self.graph.pool(), capture_error_mode='thread_local'):
                 self._step()
             self._rest_out = (self.x01, self.x02, self.x_new)
             self._caches = [g_._loop_cache for g_ in gens]      # keep the cached buffers alive with the graphs
