@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
-  const bool slab_mode = KS == 3 && !DUAL && nsplit > 1 && fin.counters != nullptr;    // block-uniform
+  const bool slab_mode = KS == 3 && nsplit > 1 && fin.counters != nullptr;    // block-uniform
   const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2 && !slab_mode;      // (DUAL has no residual)
   f32x4 rpre[2][MT][4];
   const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
     }
   }
 
-  if constexpr (KS == 3 && !DUAL) {
+  if constexpr (KS == 3) {
     if (slab_mode) {
       // ---- split-K, reduced in this launch.  Every workgroup dumps its accumulators to its slab in REGISTER order (word j of thread
       // t at [j * threads + t]: full coalesced lines, no transposition); the LAST workgroup to arrive for an output tile (arrival
@@ -554,7 +554,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       constexpr int NT = 64 * WM * WN;
       const unsigned nslots = nblocks / (unsigned)nsplit;
       const unsigned slot = ((unsigned)b * (unsigned)tiles_per_img + (unsigned)tile) * (unsigned)ntiles + (unsigned)nt;
-      const int64_t tile_words = (int64_t)NT * 32 * MT;
+      constexpr int ACC_WORDS = 32 * MT;          // accumulator words per thread and output (DUAL: the skip conv's set follows)
+      const int64_t tile_words = (int64_t)NT * ACC_WORDS * (DUAL ? 2 : 1);
       float* mine = fin.ws + ((int64_t)ksi * nslots + slot) * tile_words + tid;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -563,6 +564,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg)
             __hip_atomic_store(mine + ((m * 2 + n) * 16 + reg) * NT, acc[m][n][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (DUAL) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+              __hip_atomic_store(mine + (ACC_WORDS + (m * 2 + n) * 16 + reg) * NT, acc2[m][n][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -588,6 +598,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
               const float pv = __hip_atomic_load(src + ((m * 2 + n) * 16 + reg) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               acc[m][n][reg] = k == 0 ? pv : acc[m][n][reg] + pv;
             }
+        if (DUAL) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+              for (int reg = 0; reg < 16; ++reg) {
+                const float pv = __hip_atomic_load(src + (ACC_WORDS + (m * 2 + n) * 16 + reg) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc2[m][n][reg] = k == 0 ? pv : acc2[m][n][reg] + pv;
+              }
+        }
       }
     }
   }
@@ -1192,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(mud_conv_args a, const 
 
 // split-K needs a plain epilogue and whole, aligned float4 channel columns (the reduce kernel's access pattern)
 static bool cm_split_eligible(const mud_conv_args& a) {
-  return a.ks == 3 && !a.skip_w && !a.sub2 && !a.emul && !a.egate && a.Cout % 4 == 0 && a.Cout <= 1024 && a.ldo % 4 == 0 && (!a.res || a.ldr % 4 == 0) &&
+  return a.ks == 3 && !a.sub2 && !a.emul && !a.egate && a.Cout % 4 == 0 && a.Cout <= 1024 && a.ldo % 4 == 0 && (!a.res || a.ldr % 4 == 0) &&
          mud_aligned16(a.out) && (!a.res || mud_aligned16(a.res)) && (!a.bias || mud_aligned16(a.bias)) &&
          (!a.bias2 || (mud_aligned16(a.bias2) && a.bias2_ld % 4 == 0));
 }
@@ -1252,8 +1273,11 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
     // split-K (small grids): needs the caller's slab workspace, a plain epilogue and whole float4 channel columns
     const int64_t npix = (int64_t)a.B * a.H * a.W;
     int ns = 1;
-    if (!DUAL && a.splitk_ws && mud_aligned16(a.splitk_ws) && cm_split_eligible(a)) ns = cm_splits(nblocks, k16s);
-    if (ns > 1 && a.splitk_ws_bytes < cm_slab_bytes(ns, nblocks, 64 * WM * WN * 32 * MT)) ns = 1;      // workspace too small: run unsplit
+    static const bool two_launches = getenv("MUD_CONV_SPLITK_2LAUNCH") != nullptr;   // A/B knob
+    const bool in_launch = !two_launches && a.splitk_counters && nblocks <= a.splitk_ncounters;
+    // (the fused skip conv has two accumulator sets: only the in-launch reduction handles it)
+    if ((!DUAL || in_launch) && a.splitk_ws && mud_aligned16(a.splitk_ws) && cm_split_eligible(a)) ns = cm_splits(nblocks, k16s);
+    if (ns > 1 && a.splitk_ws_bytes < cm_slab_bytes(ns, nblocks, 64 * WM * WN * 32 * MT * (DUAL ? 2 : 1))) ns = 1;      // workspace too small: run unsplit
     if (ns > 1) {
       mud_conv_args p = a;                       // raw partial sums: no epilogue terms, output = slab ksi of the workspace
       p.out = (float*)a.splitk_ws;
@@ -1264,8 +1288,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       p.stats = nullptr;
       const int64_t stride = npix * a.Cout;
       // with arrival counters (one per output tile, zero between launches) the last workgroup of each tile reduces the slabs itself
-      static const bool two_launches = getenv("MUD_CONV_SPLITK_2LAUNCH") != nullptr;   // A/B knob
-      if (!two_launches && a.splitk_counters && nblocks <= a.splitk_ncounters) {
+      if (in_launch) {
         hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, a, tiles_x,
                            (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, (int64_t)0, CmFin{(float*)a.splitk_ws, a.splitk_counters});
         MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K, reduced in the launch)");
@@ -1335,9 +1358,16 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
 extern "C" int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* ap) {
   if (!ap || ap->ks != 3 || ap->B <= 0 || ap->H <= 0 || ap->W <= 0 || ap->Cin <= 0 || ap->Cout <= 0 || !cm_split_eligible(*ap)) return 0;
   int64_t blocks = 0;
-  const int v = cm_variant3(*ap, &blocks);
+  int v = cm_variant3(*ap, &blocks);
+  if (ap->skip_w) {                              // the fused skip conv: two accumulator sets, the in-launch reduction only, and
+    if (!ap->splitk_counters) return 0;          // mud_conv2d_mfma's tile choice (small grids take the 4-row tile)
+    if (v != CMV_8X2 && v != CMV_16X1) {
+      v = CMV_MT1;
+      blocks = mud_cdiv(ap->W, 32) * mud_cdiv(ap->H, 4) * mud_cdiv(ap->Cout, CM_BN) * ap->B;
+    }
+  }
   const int ns = cm_splits(blocks, (int)mud_cdiv(ap->Cin, 16));
-  const int tile_words = (v == CMV_8X2 || v == CMV_16X1) ? 512 * 64 : v == CMV_MT2 ? 256 * 64 : v == CMV_8X1R ? 512 * 32 : 256 * 32;   // threads x accumulators
+  const int tile_words = ((v == CMV_8X2 || v == CMV_16X1) ? 512 * 64 : v == CMV_MT2 ? 256 * 64 : v == CMV_8X1R ? 512 * 32 : 256 * 32) * (ap->skip_w ? 2 : 1);   // threads x accumulators
   return ns > 1 ? cm_slab_bytes(ns, blocks, tile_words) : 0;
 }
 

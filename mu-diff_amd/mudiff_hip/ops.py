@@ -356,12 +356,15 @@ def conv3x3_would_split_k(x: View, cout):
     return load().mud_conv2d_mfma_splitk_bytes(C.byref(a)) > 0
 
 
+FUSE_SKIP_SPLIT = os.environ.get('MUD_FUSE_SKIP_SPLIT', '1') != '0'       # A/B knob: keep the skip conv fused where the launch is split over K
+
+
 def fused_skip_ok(x: View, cout, pro_mode):
-    """Should mud_conv2d_mfma produce the block's 1x1 skip conv alongside its 3x3 conv (mud_conv_args.skip_*)?  Not where the
-    3x3 launch would otherwise be split over K (one slice at a time, 64x64 maps): the fused kernel cannot split, and a serial
-    32-chunk reduction on 128 workgroups costs more than the second read of x saves (512->256: 109 us fused vs 59 + 23 us)."""
+    """Should mud_conv2d_mfma produce the block's 1x1 skip conv alongside its 3x3 conv (mud_conv_args.skip_*)?  Where the launch
+    is split over K (one slice at a time, 64x64 maps) the fused kernel splits too - both accumulator sets go through the slabs and
+    the last workgroup of a tile reduces them (an unsplit fused launch there cost 109 us against 59 + 23 us: 512->256)."""
     return (FUSE_SKIP and pro_mode == PRO_AFFINE_SILU and x.C % 4 == 0 and 8 <= x.C <= 512 and cout % 4 == 0
-            and not conv3x3_would_split_k(x, cout))
+            and (FUSE_SKIP_SPLIT or not conv3x3_would_split_k(x, cout)))
 
 
 def resolve_pro(pro):
@@ -476,12 +479,12 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
         a.skip_w, a.skip_bias, a.skip_out, a.skip_ldo = ptr(sw), ptr(sb), so.ptr, so.ld
         skip_flops = 2.0 * x.B * Ho * Wo * Cout * x.C
     if mfma and ks == 3:          # small grids (one slice at a time): split-K slabs, stream-ordered scratch (graph-capture safe)
+        cnt = splitk_counters(x.device)
+        a.splitk_counters, a.splitk_ncounters = ptr(cnt), cnt.numel()
         nws = lib.mud_conv2d_mfma_splitk_bytes(C.byref(a))
         if nws > 0:
             keep = (keep, torch.empty(nws, device=x.device, dtype=torch.uint8))
             a.splitk_ws, a.splitk_ws_bytes = ptr(keep[1]), nws
-            cnt = splitk_counters(x.device)
-            a.splitk_counters, a.splitk_ncounters = ptr(cnt), cnt.numel()
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
     name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks + skip_flops     # algorithmic (sub2 issues 4x this)

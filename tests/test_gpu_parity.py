@@ -301,13 +301,13 @@ def test_conv_with_fused_skip_conv(B, H, W, Cin, Cout):
     bias, bias_s, b2 = torch.randn(Cout, generator=gen), torch.randn(Cout, generator=gen), torch.randn(B, Cout, generator=gen)
     sc, sh = torch.rand(B, Cin, generator=gen) + 0.5, torch.randn(B, Cin, generator=gen)
     xv, wp, w2p = ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ops.pack_conv_weight(g(w2))
-    assert ops.fused_skip_ok(xv, Cout, ops.PRO_AFFINE_SILU) == (not ops.conv3x3_would_split_k(xv, Cout))      # (the model fuses only where the launch would not be split over K)
+    assert ops.fused_skip_ok(xv, Cout, ops.PRO_AFFINE_SILU)       # (also where the launch is split over K: both accumulator sets go through the slabs)
     arena = ops.StatsArena(torch.device(DEV))
     out, skip = ops.View.empty(B, H, W, Cout, DEV, arena), ops.View.empty(B, H, W, Cout + 8, DEV).slice(4, Cout)
     pro = (g(sc), g(sh), ops.PRO_AFFINE_SILU)
     ops.conv(xv, wp, 3, Cout, mfma=True, pro=pro, bias=g(bias), bias2=g(b2), out=out, skip=(w2p, g(bias_s), skip))
     plain = ops.conv(xv, wp, 3, Cout, mfma=True, pro=pro, bias=g(bias), bias2=g(b2))
-    assert maxdiff(out.to_nchw(), plain.to_nchw()) <= 2e-5         # (a small grid runs the unfused launch split-K: another summation order)
+    assert maxdiff(out.to_nchw(), plain.to_nchw()) <= 2e-5         # (the two launches may pick different tiles / K splits: another summation order)
     h = F.silu(x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None])
     ref = F.conv2d(h, w.double(), bias.double(), padding=1) + b2.double()[:, :, None, None]
     ref_s = F.conv2d(x.double(), w2.double(), bias_s.double())
@@ -315,6 +315,13 @@ def test_conv_with_fused_skip_conv(B, H, W, Cin, Cout):
     print(f'fused skip conv {B}x{H}x{W} {Cin}->{Cout}: 3x3 {e1:.2e}, 1x1 skip {e2:.2e} vs fp64')
     assert e1 <= 1e-4 and e2 <= 1e-4
     assert maxdiff(out.stats[..., 0], ref.sum(dim=(2, 3))) <= 2e-6 * float(ref.abs().sum(dim=(2, 3)).max())
+    if ops.conv3x3_would_split_k(xv, Cout):                         # the fused launch split over K: the same bits whoever arrives last
+        first, first_s = out.to_nchw().clone(), skip.to_nchw().clone()
+        out2, skip2 = ops.View.empty(B, H, W, Cout, DEV), ops.View.empty(B, H, W, Cout, DEV)
+        for _ in range(3):
+            ops.conv(xv, wp, 3, Cout, mfma=True, pro=pro, bias=g(bias), bias2=g(b2), out=out2, skip=(w2p, g(bias_s), skip2))
+            assert torch.equal(out2.to_nchw(), first) and torch.equal(skip2.to_nchw(), first_s)
+        assert int(ops.splitk_counters(torch.device(DEV)).abs().sum()) == 0
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 64, 64, 256, 256), (1, 64, 64, 512, 256), (1, 32, 32, 384, 128), (1, 40, 24, 320, 64), (4, 64, 64, 256, 256)])
