@@ -90,3 +90,19 @@ def test_seeded_state_dict_equals_the_fixture_weight_table(which):
     ours, ref = seeded_state_dict(m, which, 1234, cfg.fourier_scale), O.make_state_dict(cfg, which, 1234)
     assert list(ours) == list(ref)
     assert all(torch.equal(ours[k], ref[k]) for k in ref)
+
+
+@pytest.mark.gpu
+def test_two_real_ranks_on_the_gpu_box():
+    """The REAL multi-rank worker (models, parameter broadcast, hipGraph capture next to a live process group, barrier, MAX over
+    ranks, rank-0 line) with two ranks sharing cuda:0 over gloo - every line of the N-rank path except RCCL itself, which needs
+    one GPU per rank.  Weak (2 x 2 slices) and strong (5 slices over 2 ranks, ragged tail batch)."""
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'MUDIFF_BENCH_DRYRUN')}
+    e.update(MUDIFF_BENCH_BACKEND='gloo', MUDIFF_BENCH_SAME_GPU='1')
+    common = ['--gpus', '2', '--batch', '2', '--steps', '1', '--warmup', '1', '--no-extras', '--no-cpu-baseline', '--no-roofline']
+    for extra, scaling in (([], 'weak'), (['--total-slices', '5'], 'strong')):
+        p = subprocess.run([sys.executable, BENCH, *common, *extra], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = _line(p)
+        assert d['n_gpus'] == 2 and d['ranks_seen'] == [0, 1] and d['scaling'] == scaling and d['value'] > 0
+        assert d['config']['hipgraph'] is True
