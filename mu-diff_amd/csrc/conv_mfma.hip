@@ -47,6 +47,7 @@
 #define CM_WHATIF 0              // TIMING PROBES (wrong results): 1 = no prologue arithmetic in the staging, 2 = no activation loads,
 #endif                           // 3 = no weight DMA, 4 = no MFMAs, 5 = no staging at all (no loads, no arithmetic, no LDS writes),
                                  // 6 / 7 / 8 = fragment reads only in the first tap of a 3-tap group: all / A only kept / B only kept
+                                 // 9 / 10 = two / one and a half MFMAs per product instead of three (what cheaper cross terms could buy)
 #ifndef CM_PRE_RES_ALL
 #define CM_PRE_RES_ALL 0         // 1: the 4-wave tiles prefetch the residual tile too (experiment)
 #endif
@@ -486,6 +487,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
+#elif CM_WHATIF == 9 || CM_WHATIF == 10   // TIMING PROBE (wrong results): 2 (9) or 1.5 (10) MFMAs per product, all fragment reads kept
+            asm volatile("" :: "v"(al), "v"(bl[1]));
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
+#if CM_WHATIF == 9
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[m][1], 0, 0, 0);
+#endif
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
 #elif CM_ORDER == 2    // term by term, the two accumulators alternate: no back-to-back MFMAs on one accumulator (64->64 layers -2 %,
                        // others +-0: profiles/r02_l_ab_mfma_order.txt); each accumulator still adds its terms in the order lo.hi, hi.lo, hi.hi
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
