@@ -160,11 +160,12 @@ def sample_from_model(coefficients, generator1, cond1, generator2, cond2, cond3,
 
 class GraphSampler:
     """One reverse step (G1 -> G2 -> dual posterior) captured into a hipGraph for a fixed [B,1,H,W] and
-    replayed: removes the per-launch host cost of the ~700 kernels of a step.  Noise is drawn on the
+    replayed: removes the per-launch host cost of the ~200 kernels of a step.  Noise is drawn on the
     device into static buffers before each replay (or injected for parity runs)."""
 
     def __init__(self, coefficients, generator1, generator2, opt, B, H, W, device, warmup=2):
         self.coef, self.g1, self.g2, self.opt = coefficients, generator1, generator2, opt
+        self.B, self.H, self.W = int(B), int(H), int(W)
         self.n_time = None
         dev = torch.device(device)
         f = dict(device=dev, dtype=torch.float32)

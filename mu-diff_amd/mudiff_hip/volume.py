@@ -181,9 +181,12 @@ def load_checkpoint(template, net, name, device):
 # batched sampling of a stack of slices
 # ---------------------------------------------------------------------------------------------------
 def predict_slices(args, gen1, gen2, cond_stacks, device, batch_size=32, x_inits=None, zs=None, noises=None, seed=None,
-                   use_graph=True, progress=None):
+                   use_graph=True, progress=None, sampler=None):
     """cond_stacks: three float arrays [n,X,Y] in [-1,1] (the condition contrasts, already normalised and sliced).
     -> [n,S,S] float32 numpy in [0,1], S = args.image_size.
+
+    `sampler`: a sampling.GraphSampler built for these generators (any batch size, image_size x image_size) to reuse across
+    volumes - warm-up and the two hipGraph captures are then paid once per process instead of once per volume.
 
     x_inits [n,1,S,S] / zs (per step [n,nz]) / noises (per step [n,1,S,S]) inject the Gaussian draws per slice for
     parity runs; otherwise they are drawn on the device (seeded by `seed` when given)."""
@@ -205,7 +208,12 @@ def predict_slices(args, gen1, gen2, cond_stacks, device, batch_size=32, x_inits
         gen = torch.Generator(device=device).manual_seed(int(seed))
     T = int(args.num_timesteps)
     bs = min(int(batch_size), n)
-    sampler = S.GraphSampler(coef, gen1, gen2, args, bs, size, size, device) if use_graph else None
+    if sampler is not None:
+        if (sampler.H, sampler.W) != (size, size) or sampler.g1 is not gen1 or sampler.g2 is not gen2:
+            raise ValueError('predict_slices: the sampler was built for other generators or another image size')
+        bs = sampler.B                           # (a short last batch is padded to the captured shape either way)
+    elif use_graph:
+        sampler = S.GraphSampler(coef, gen1, gen2, args, bs, size, size, device)
     out = torch.empty(n, size, size, device=device, dtype=torch.float32)
 
     def padded(t, lo, hi):      # the last batch is padded by repeating its last slice (fixed graph shape), trimmed afterwards

@@ -862,6 +862,15 @@ def test_volume_slices_batched_vs_per_slice_oracle(use_graph):
     err = max(float(np.abs(got[i] - want[i]).max()) for i in range(5))
     print(f'volume slices (graph={use_graph}): max-abs {err:.2e}')
     assert err <= 1e-3 and got.min() >= 0.0 and got.max() <= 1.0
+    if use_graph:       # one sampler reused across volumes (capture paid once): what a sampler built per call gives (to the fp64-atomic GroupNorm sums' run-to-run jitter)
+        from mudiff_hip import sampling as S
+        smp = S.GraphSampler(S.Posterior_Coefficients(cfg, DEV), g1, g2, cfg, 2, cfg.image_size, cfg.image_size, DEV)
+        for _ in range(2):
+            again = V.predict_slices(cfg, g1, g2, stacks, DEV, batch_size=32, x_inits=x_inits, zs=zs, noises=noises, sampler=smp)
+            assert float(np.abs(again - got).max()) <= 1e-4
+        other, _ = _build(cfg, seed=10)
+        with pytest.raises(ValueError):
+            V.predict_slices(cfg, other, g2, stacks, DEV, x_inits=x_inits, zs=zs, noises=noises, sampler=smp)
 
 
 def test_predict_volume_end_to_end_nifti(tmp_path):
