@@ -75,6 +75,16 @@ state = {'a': 'fp32', 'w': 'fp32'}
 
 def patched(x, w, *args, **kw):
     if w.shape[-1] == 3 and w.shape[1] % 4 == 0 and w.shape[1] >= 16:
+        if state['a'] == 'crossc:e4m3':              # the same with CONSTANT power-of-two scales per operand class (tap-packed K: no per-pixel block scale)
+            bias = args[0] if args else kw.pop('bias', None)
+            rest = args[1:] if args else ()
+            xh, wh = x.half().float(), w.half().float()
+            xl, wl = x - xh, w - wh
+            kw_ = float(2.0 ** (7 - torch.ceil(torch.log2(w.abs().max())).item()))      # max |w| * kw_ in (64, 128]
+            qc = lambda t, sc: q_elem(t * sc, 'e4m3') / sc
+            y = orig(xh, wh, bias, *rest, **kw)
+            y = y + orig(qc(xl, 2.0 ** 14), qc(wh, kw_), None, *rest, **kw)
+            return y + orig(qc(xh, 4.0), qc(wl, kw_ * 4096.0), None, *rest, **kw)
         if state['a'].startswith('cross:'):          # fp16 hi.hi + the two cross terms in an MX element format (the proposal of DESIGN section 9)
             fmt = state['a'].split(':')[1]
             bias = args[0] if args else kw.pop('bias', None)
@@ -93,7 +103,7 @@ O.F.conv2d = patched
 
 def main():
     print('activations / weights of the 3x3 convs rounded to ...   max-abs per step vs the reference\'s recorded outputs (x01, x02, x_new)')
-    cases = (('fp32', 'fp32'), ('bf16x2', 'bf16x2'), ('cross:e4m3', '-'), ('cross:e2m3', '-'), ('cross:e5m2', '-'), ('fp16', 'fp32'), ('fp32', 'fp16'), ('fp16', 'fp16'), ('tf32', 'tf32'), ('bf16', 'fp32'))
+    cases = (('fp32', 'fp32'), ('bf16x2', 'bf16x2'), ('cross:e4m3', '-'), ('crossc:e4m3', '-'), ('cross:e2m3', '-'), ('cross:e5m2', '-'), ('fp16', 'fp32'), ('fp32', 'fp16'), ('fp16', 'fp16'), ('tf32', 'tf32'), ('bf16', 'fp32'))
     if os.environ.get('ONLY'):
         cases = tuple(c for c in cases if c[0] in os.environ['ONLY'].split(','))
     for fa, fw in cases:
