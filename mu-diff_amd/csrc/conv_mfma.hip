@@ -31,6 +31,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 #ifndef CM_STAGGER
 #define CM_STAGGER 0             // experiment knobs (scripts/build_variants.py); the shipped values are set here
 #endif
@@ -48,6 +50,7 @@
 #endif                           // 3 = no weight DMA, 4 = no MFMAs, 5 = no staging at all (no loads, no arithmetic, no LDS writes),
                                  // 6 / 7 / 8 = fragment reads only in the first tap of a 3-tap group: all / A only kept / B only kept
                                  // 9 / 10 = two / one and a half MFMAs per product instead of three (what cheaper cross terms could buy)
+                                 // 11 = hi.hi per tap + both cross terms as two block-scaled fp8 MFMAs per 3-tap group (the section-9 layout)
 #ifndef CM_PRE_RES_ALL
 #define CM_PRE_RES_ALL 0         // 1: the 4-wave tiles prefetch the residual tile too (experiment)
 #endif
@@ -487,6 +490,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
+#elif CM_WHATIF == 11
+            // TIMING PROBE (wrong results): per tap ONE 16-bit MFMA (hi.hi); behind the group's last tap the two cross terms as two
+            // block-scaled fp8 MFMAs per accumulator (K = 64 = 3 taps + a zero tap, x 16 channels), their 32-byte operands read as
+            // 2 x 16 B from the places the e4m3 images would occupy (today's lo halves) - see the block behind the m loop
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);     // (the per-tap lo reads are dead here, as they would be)
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
 #elif CM_WHATIF == 9 || CM_WHATIF == 10   // TIMING PROBE (wrong results): 2 (9) or 1.5 (10) MFMAs per product, all fragment reads kept
             asm volatile("" :: "v"(al), "v"(bl[1]));
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
@@ -531,6 +540,30 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             }
 #endif
           }
+#if CM_WHATIF == 11
+          if (KS == 3 && sg == G::GS - 1) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              i32x8 xb[2];
+#pragma unroll
+              for (int n = 0; n < 2; ++n) {
+                const i32x4 q0 = *(const i32x4*)(bcur + c * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
+                const i32x4 q1 = *(const i32x4*)(bcur + (c + 1) * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
+                xb[n] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+              }
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                const int t0 = g * G::GS + c, t1 = t0 + 1;
+                const i32x4 p0 = *(const i32x4*)(cur + lane_a + ((m + t0 / KS) * G::PW + t0 % KS) * CM_PIX + 32);
+                const i32x4 p1 = *(const i32x4*)(cur + lane_a + ((m + t1 / KS) * G::PW + t1 % KS) * CM_PIX + 32);
+                const i32x8 xa = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                  acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb[n], acc[m][n], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+              }
+            }
+          }
+#endif
         }
         // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),
         // so the conversion VALU work interleaves with matrix work instead of forming one long MFMA-free stretch
