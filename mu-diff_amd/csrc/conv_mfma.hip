@@ -33,6 +33,24 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef CM_FP8X
+#define CM_FP8X 0                // EXPERIMENT, 3x3 kernel only: fp16 hi.hi per tap + the two cross terms of a 3-tap
+#endif                           // group as two block-scaled e4m3 MFMAs (K = 3 taps + a zero tap, x 16 channels).  Same LDS images and weight steps:
+                                 // pixel record [f16 hi 32 B][e4m3 a*2^2 16 B][e4m3 a_lo*2^14 16 B], weight step [f16 hi 2 KiB][e4m3 w*2^7 1 KiB][e4m3 w_lo*2^19 1 KiB]
+#define CM_X_SA 2                // constant power-of-two pre-scales of the e4m3 images (undone by the MFMA's E8M0 scale operands)
+#define CM_X_SAL 14
+#define CM_X_SW 7
+#define CM_X_SWL 19
+__device__ __forceinline__ int cm_e4m3x4(f32x4 v, float scale) {    // 4 floats * scale -> 4 packed OCP e4m3 bytes (hardware converter)
+  // v_cvt_pk_fp8_f32 does NOT saturate: |x| >= 480 comes out as NaN (scripts/mfma_f8_layout.hip), so out-of-range values are clamped to +-448 first
+  v = v * scale;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -448.0f, 448.0f);
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true);
+}
 #ifndef CM_STAGGER
 #define CM_STAGGER 0             // experiment knobs (scripts/build_variants.py); the shipped values are set here
 #endif
@@ -276,10 +294,20 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
+#if CM_FP8X
+      {
+        const f16x4 hi = __builtin_convertvector(v, f16x4);
+        const f32x4 lo = v - __builtin_convertvector(hi, f32x4);
+        *(f16x4*)(buf + loff[j]) = hi;
+        *(int*)(buf + loff[j] + 32 - q * 4) = cm_e4m3x4(v, (float)(1 << CM_X_SA));         // record + 32 + 4 q   (loff holds record + 8 q)
+        *(int*)(buf + loff[j] + 48 - q * 4) = cm_e4m3x4(lo, (float)(1 << CM_X_SAL));        // record + 48 + 4 q
+      }
+#else
       const bf16x4 hi = __builtin_convertvector(v, bf16x4);
       const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
       *(bf16x4*)(buf + loff[j]) = hi;
       *(bf16x4*)(buf + loff[j] + 32) = lo;
+#endif
       if (DUAL) {                               // the RAW value of the tile's centre pixels: A operand of the 1x1 skip conv
         if (loff2[j] >= 0) {
           const f32x4 rv = raw[j] * (cvalid ? 1.0f : 0.0f);
@@ -330,6 +358,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   };
 
   const int lane_a = ((KS == 3) ? (wm * MT * G::PW + r) : (wm * MT * 32 + r)) * CM_PIX + hh * 16;
+#if CM_FP8X
+  const int xa_lane0 = lane_a - hh * 16 + hh * (2 * CM_PIX);                       // e4m3 operand, first 16 bytes: the record of tap 0 (hh = 0) / tap 2 (hh = 1)
+  const int xa_lane1_t0 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 48);  // second 16 bytes, term 0 (a_lo image at +48): tap 1 / zero padding of tap 2's record
+  const int xa_lane1_t1 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 32);  // term 1 (a image at +32)
+  const int xb_lane = r * 16 + hh * (2 * CM_BSTEP);
+#endif
   f32x16 acc[MT][2];
   f32x16 acc2[DUAL ? MT : 1][2];                // DUAL: the 1x1 skip conv of the raw input
 #pragma unroll
@@ -344,6 +378,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   const int lane_a2 = ((wm * MT) * 32 + r) * 64 + ((hh ^ ((r >> 2) & 3)) << 4);   // DUAL: this lane's hi unit in the raw centre image (row m adds 32 * 64)
 
   // ---- prologue: chunk 0 into A buffer 0, B group 0 into ring slot 0
+#if CM_FP8X
+  if (q == 0) {      // bytes 64..79 of every pixel record in both A buffers: the zero tap of the cross-term MFMAs (never written again)
+#pragma unroll
+    for (int j = 0; j < G::NLOAD; ++j) {
+      *(i32x4*)(smem + loff[j] + 64) = i32x4{0, 0, 0, 0};
+      *(i32x4*)(smem + G::BUF + loff[j] + 64) = i32x4{0, 0, 0, 0};
+    }
+  }
+#endif
   dma_b(kc0 * G::NG);
   dma_b2(kc0);
   fetch_raw(kc0);
@@ -490,6 +533,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
+#elif CM_FP8X
+            {   // hi.hi in fp16 (the same fragment places as the bf16 hi halves); the cross terms follow the group's last tap
+              const f16x8 ah16 = __builtin_bit_cast(f16x8, ah);
+              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, __builtin_bit_cast(f16x8, bh[0]), acc[m][0], 0, 0, 0);
+              acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, __builtin_bit_cast(f16x8, bh[1]), acc[m][1], 0, 0, 0);
+            }
 #elif CM_WHATIF == 11
             // TIMING PROBE (wrong results): per tap ONE 16-bit MFMA (hi.hi); behind the group's last tap the two cross terms as two
             // block-scaled fp8 MFMAs per accumulator (K = 64 = 3 taps + a zero tap, x 16 channels), their 32-byte operands read as
@@ -540,7 +589,45 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             }
 #endif
           }
-#if CM_WHATIF == 11
+#if CM_FP8X
+          if (KS == 3 && sg == G::GS - 1) {
+            // cross terms of this 3-tap group: K = 64 = (tap 0, tap 1 | tap 2, zero) x 16 channels; lane half hh owns K [32 hh, 32 hh + 32)
+            // (operand map checked by scripts/mfma_f8_layout.hip).  The e4m3 images were pre-scaled by constant powers of two, which the
+            // E8M0 scale operands (2^(byte - 127), the same in every byte) take back out, so both terms add straight into acc.
+            // The zero tap lives on the A side: bytes 64..79 of every pixel record (its padding) are zeroed once per workgroup, and lane
+            // half 1 reads them as its second 16 bytes, so no operand needs a select; its B bytes there are tap 1's (finite e4m3, times 0).
+            constexpr int E_A = 127 - CM_X_SA, E_AL = 127 - CM_X_SAL, E_W = 127 - CM_X_SW, E_WL = 127 - CM_X_SWL;
+            constexpr int S_A = E_A * 0x01010101, S_AL = E_AL * 0x01010101, S_W = E_W * 0x01010101, S_WL = E_WL * 0x01010101;
+            // every address is one of a few per-lane bases (the lane-half dependence folded in, computed before the K loop) + a compile-time
+            // offset, as the rest of the loop's LDS reads are: hh-dependent offsets per (group, term, row) cost ~60 address registers
+            const char* brow = bcur + xb_lane;                                // this lane's 16 input channels of output channel r: tap 0 (hh = 0) / tap 2 (hh = 1)
+            const char* brow1 = bcur + CM_BSTEP + r * 16;                     // tap 1
+            const int o0 = ((g * G::GS) / KS * G::PW + (g * G::GS) % KS) * CM_PIX;      // the group's first tap (taps 3g, 3g+1, 3g+2 are one row: +80, +160 bytes)
+#pragma unroll
+            for (int term = 0; term < 2; ++term) {
+              const int wplane = CM_BPLANE + term * 1024, aoff = term ? 32 : 48;      // term 0: a_lo . w_hi, term 1: a_hi . w_lo
+              const char* pa0 = cur + xa_lane0 + o0 + aoff;                           // first 16 bytes: tap 0 / tap 2
+              const char* pa1 = cur + (term ? xa_lane1_t1 : xa_lane1_t0) + o0;        // second: tap 1 / the record's zero padding
+              i32x8 wq[2];
+#pragma unroll
+              for (int n = 0; n < 2; ++n) {
+                const i32x4 q0 = *(const i32x4*)(brow + wplane + n * 512);
+                const i32x4 q1 = *(const i32x4*)(brow1 + wplane + n * 512);
+                wq[n] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+              }
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                const i32x4 p0 = *(const i32x4*)(pa0 + m * G::PW * CM_PIX);
+                const i32x4 p1 = *(const i32x4*)(pa1 + m * G::PW * CM_PIX);
+                const i32x8 aq = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                  acc[m][n] = term ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, S_A, 0, S_WL)
+                                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, S_AL, 0, S_W);
+              }
+            }
+          }
+#elif CM_WHATIF == 11
           if (KS == 3 && sg == G::GS - 1) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -1174,6 +1261,31 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     }
     char* base = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP + co_l * 32 +
                  ((h2 ^ ((co_l >> 3) & 1)) << 4);   // 16-B halves swapped on rows with bit 3 set: the image is copied verbatim to LDS
+#if CM_FP8X
+    if (taps == 9) {      // 3x3 operand of the experiment: [f16 hi plane 2 KiB, same places][e4m3 w * 2^7: [2 n][32 co][16 ci]][e4m3 w_lo * 2^19: the same]
+      f16x8 h16;
+      f32x4 w0, w1, l0, l1;
+      float vv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+        if (co < Cout && ci0 + j < Cin) v = src[(int64_t)b * src_bstride + tap * s_tap + (int64_t)(ci0 + j) * s_ci + (int64_t)co * s_co];
+        vv[j] = v;
+        h16[j] = (_Float16)v;
+      }
+      w0 = f32x4{vv[0], vv[1], vv[2], vv[3]}; w1 = f32x4{vv[4], vv[5], vv[6], vv[7]};
+      l0 = f32x4{vv[0] - (float)h16[0], vv[1] - (float)h16[1], vv[2] - (float)h16[2], vv[3] - (float)h16[3]};
+      l1 = f32x4{vv[4] - (float)h16[4], vv[5] - (float)h16[5], vv[6] - (float)h16[6], vv[7] - (float)h16[7]};
+      *(f16x8*)base = h16;
+      char* step = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP;
+      char* row8 = step + CM_BPLANE + (co_l >> 5) * 512 + (co_l & 31) * 16 + h2 * 8;
+      *(int*)(row8) = cm_e4m3x4(w0, (float)(1 << CM_X_SW));
+      *(int*)(row8 + 4) = cm_e4m3x4(w1, (float)(1 << CM_X_SW));
+      *(int*)(row8 + 1024) = cm_e4m3x4(l0, (float)(1 << CM_X_SWL));
+      *(int*)(row8 + 1024 + 4) = cm_e4m3x4(l1, (float)(1 << CM_X_SWL));
+      continue;
+    }
+#endif
     *(bf16x8*)base = hi;
     *(bf16x8*)(base + CM_BPLANE) = lo;
   }
