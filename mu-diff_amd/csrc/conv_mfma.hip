@@ -626,6 +626,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
                                    : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, S_AL, 0, S_W);
               }
             }
+            // (as compiled by hipcc 7.2 all twelve operand reads of the group are issued ahead of its barrier and the four MFMAs sink below it,
+            //  behind the next weight DMA: 48 registers live across the barrier; __builtin_amdgcn_sched_barrier fences here or between the terms
+            //  do not change the allocation - DESIGN.md section 9 item 5)
           }
 #elif CM_WHATIF == 11
           if (KS == 3 && sg == G::GS - 1) {
