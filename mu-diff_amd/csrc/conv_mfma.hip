@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
                    mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
                    (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
   const bool slab_mode = KS == 3 && nsplit > 1 && fin.counters != nullptr;    // block-uniform
-  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2 && !slab_mode;      // (DUAL has no residual)
+  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2 && !slab_mode && !CM_FP8X;      // (the experiment needs the 64 prefetch registers: with them the two-row tiles spill 120-193)      // (DUAL has no residual)
   f32x4 rpre[2][MT][4];
   const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
   auto prefetch_res = [&]() {
@@ -1502,7 +1502,7 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
   // 79 KiB of LDS and 110 VGPRs, so two workgroups share a CU (four waves per SIMD) and one's residual / store phase runs
   // under the other's K loop.  Measured against the 16-row tile (profiles/r02_j_ab_8x1row.txt): with a residual 330 -> 305 us,
   // without 307 -> 303 us; deeper reductions (128 / 192 / 256 -> 64) are equal, so they keep the tile with less halo.
-  static const bool no8x1r = getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob
+  static const bool no8x1r = CM_FP8X || getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob (the experiment's one-row 8-wave tile spills at its 128-register cap)
   if (!no8x1r && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
   else if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
   else if (!no16 && a.H >= 16 && blocks16 >= 256) v = CMV_16X1, nb = blocks16;
