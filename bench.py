@@ -63,11 +63,14 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '16')), help='slices per GPU per captured reverse step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('MUDIFF_BENCH_BATCH', '32')),
+                    help='slices per GPU per captured reverse step (default 32 = BASELINE config 3)')
     ap.add_argument('--total-slices', type=int, default=0, help='strong scaling: a step is one pass over this many slices sharded over the ranks')
     ap.add_argument('--sweep', default='', help='comma-separated GPU counts, e.g. 1,2,4,8: strong-scaling curve + CPU baseline in one line')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-full', action='store_true',
+                    help='BASELINE.md section 3 in full: adds the 1-thread figure and B=8 to the default (all cores, B=1, 2 warm-up + 3 timed slices); ~10 min')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the parity / batch1 / batch32 / pcie legs')
     return ap.parse_args(argv)
@@ -99,7 +102,11 @@ def last_json_line(text):
 
 def launch_ranks(n, argv, extra_env=None, timeout=None):
     """Start n rank processes of this script (one per GPU) and wait.  -> (returncode, rank-0 stdout).
-    Any rank failing terminates the others (exactly the PIDs started here) and the result is non-zero."""
+    Any rank failing terminates the others (exactly the PIDs started here) and the result is non-zero.
+    timeout: seconds (default MUDIFF_BENCH_TIMEOUT, 1500): a rank hung in the RCCL rendezvous or in a barrier must not
+    hold the GPUs until an outer driver kills the launcher - the ranks started here are stopped and the result is 124."""
+    if timeout is None:
+        timeout = float(os.environ.get('MUDIFF_BENCH_TIMEOUT', '1500'))
     port = _free_port()
     procs = []
     for r in range(n):
@@ -163,14 +170,15 @@ def run_sweep(a, argv):
         elif not x.startswith(('--sweep=', '--gpus=', '--total-slices=')):
             clean.append(x)
     curve, lines, skipped, rc_all = {}, {}, [], 0
+    have_extras = False                                    # cpu_baseline + roofline ride on the first run that SUCCEEDS
     for n in counts:
         if n > have:
             skipped.append(n)
             continue
         args = clean + ['--gpus', str(n), '--total-slices', str(total), '--no-extras']
-        if n != counts[0] or a.no_cpu_baseline:
+        if have_extras or a.no_cpu_baseline:
             args.append('--no-cpu-baseline')
-        if n != counts[0]:
+        if have_extras:
             args.append('--no-roofline')
         log(f'sweep: {n} GPU(s) ...')
         if n == 1:
@@ -186,12 +194,17 @@ def run_sweep(a, argv):
             continue
         curve[str(n)] = line['value']
         lines[str(n)] = line
-    first = lines.get(str(counts[0])) or (next(iter(lines.values())) if lines else {})
+        have_extras = True
+    first = next(iter(lines.values())) if lines else {}
     out = {'metric': METRIC, 'unit': 'slices/s', 'higher_is_better': True, 'scaling': 'strong', 'data': 'synthetic',
            'total_slices': total, 'slices_per_s_by_gpus': curve,
            'value': max(curve.values()) if curve else None, 'n_gpus': max((int(k) for k in curve), default=0),
            'ms_per_step_by_gpus': {k: v['ms_per_step'] for k, v in lines.items()},
            'ranks_seen_by_gpus': {k: v.get('ranks_seen') for k, v in lines.items()},
+           'per_rank_by_gpus': {k: v.get('per_rank') for k, v in lines.items() if v.get('per_rank')},
+           'param_broadcast_by_gpus': {k: v.get('param_broadcast') for k, v in lines.items() if v.get('param_broadcast')},
+           # strong scaling: value(n) / (n x value(1)), only when the 1-GPU point ran in this sweep (the driver computes its own)
+           'efficiency_vs_1gpu': ({k: round(v / (int(k) * curve['1']), 4) for k, v in curve.items()} if curve.get('1') else None),
            'skipped_gpu_counts': skipped, 'visible_gpus': have, 'steps': a.steps, 'warmup': a.warmup,
            'dtype': first.get('dtype'), 'config': first.get('config'), 'vs_baseline': None,
            'cpu_baseline': first.get('cpu_baseline'), 'roofline': first.get('roofline')}
@@ -252,12 +265,41 @@ def build_models(cfg, dev, rank, world):
         random_weights_(g1, 1)
         random_weights_(g2, 2)
     g1, g2 = g1.to(dev).eval(), g2.to(dev).eval()
+    bcast = None
     if world > 1:
         # parameters live on rank 0 (checkpoint reader); one flattened RCCL broadcast per generator over xGMI
-        from mudiff_hip.distributed import broadcast_parameters
-        broadcast_parameters(g1, src=0)
-        broadcast_parameters(g2, src=0)
-    return g1, g2
+        bcast = timed_broadcast([g1, g2], dev)
+    return g1, g2, bcast
+
+
+def timed_broadcast(modules, dev):
+    """The load-time parameter broadcast (north_star: "RCCL broadcast of params over xGMI at load only"; reference
+    engine/train.py:188-190 sends every tensor separately): one flattened message per module.  -> bytes, wall ms (MAX over
+    ranks, barrier on both sides; the first collective of a process group also pays the communicator set-up) and GB/s."""
+    import torch.distributed as dist
+    from mudiff_hip.distributed import broadcast_parameters, max_over_ranks
+    cuda = torch.device(dev).type == 'cuda'
+    dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbytes = sum(broadcast_parameters(m, src=0) for m in modules)
+    if cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    ms = 1e3 * max_over_ranks(time.perf_counter() - t0, dev)
+    return {'bytes': int(nbytes), 'messages': len(modules), 'ms': round(ms, 3), 'gb_per_s': round(nbytes / ms / 1e6, 3) if ms > 0 else None,
+            'note': 'one flattened broadcast per generator from rank 0, includes communicator set-up of the first collective'}
+
+
+def per_rank_rates(slices_local, dt_local, dev, world):
+    """Every rank's own slices/s over its own timed region (all_gather), next to the MAX-over-ranks headline."""
+    import torch.distributed as dist
+    mine = torch.tensor([slices_local / dt_local], dtype=torch.float64, device=dev)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    rates = [round(float(t.item()), 3) for t in got]
+    return {'slices_per_s': rates, 'min': min(rates), 'max': max(rates)}
 
 
 def synthetic_batch(cfg, B, dev, seed):
@@ -275,30 +317,64 @@ def synthetic_batch(cfg, B, dev, seed):
     return out
 
 
-def cpu_baseline(cfg):
+def cpu_baseline(cfg, full=False):
+    """SURVEY.md section 8(d) / BASELINE.md section 3: the CPU oracle (the reference's PyTorch-CPU path restated; checker code,
+    timed here and nowhere shipped) on this host's cores.  Default: all cores, B=1, 2 warm-up slices + 3 timed slices
+    (value = 3 / their total time).  full=True adds the 1-thread figure (1 warm-up forward + 1 timed slice) and B=8
+    (one timed batch after a 1-forward warm-up)."""
+    import platform
     from oracle import mudiff_oracle as O
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         ncores = os.cpu_count() or 1
     ncores = max(1, min(ncores, int(os.environ.get('MUDIFF_CPU_THREADS', '16'))))   # the 1-GPU box's CPU share is 16
-    torch.set_num_threads(ncores)
     sd1, sd2 = O.make_state_dict(cfg, 'g1', 1234), O.make_state_dict(cfg, 'g2', 1234)
-    g = torch.Generator().manual_seed(5)
-    H = cfg.image_size
-    conds = [torch.tanh(torch.randn(1, 1, H, H, generator=g)) for _ in range(3)]
-    x0 = torch.randn(1, 1, H, H, generator=g)
-    zs = [torch.randn(1, cfg.nz, generator=g) for _ in range(cfg.num_timesteps)]
-    ns = [torch.randn(1, 1, H, H, generator=g) for _ in range(cfg.num_timesteps)]
+    H, T = cfg.image_size, cfg.num_timesteps
     coef = O.PosteriorCoefficients(cfg)
-    with torch.no_grad():
-        O.g1_forward(sd1, cfg, x0, *conds, torch.zeros(1, dtype=torch.int64), zs[0])      # warm-up (thread pool, oneDNN primitives)
+
+    def draws(B, seed):
+        g = torch.Generator().manual_seed(seed)
+        conds = [torch.tanh(torch.randn(B, 1, H, H, generator=g)) for _ in range(3)]
+        x0 = torch.randn(B, 1, H, H, generator=g)
+        return conds, x0, [torch.randn(B, cfg.nz, generator=g) for _ in range(T)], [torch.randn(B, 1, H, H, generator=g) for _ in range(T)]
+
+    def run(B, seed):
+        conds, x0, zs, ns = draws(B, seed)
         t0 = time.perf_counter()
         O.sample_from_model(coef, sd1, sd2, cfg, *conds, x0, zs, ns)
-        dt = time.perf_counter() - t0
-    return dict(value=round(1.0 / dt, 5), unit='slices/s', cores=ncores, kind='port',
-                sample=f'1 slice (B=1, {cfg.num_timesteps} steps, both generators, 256x256, nf=64) after a 1-forward warm-up; '
-                       f'{dt:.2f} s; torch {torch.__version__} CPU fp32')
+        return time.perf_counter() - t0
+
+    def warm_forward(B):
+        conds, x0, zs, _ = draws(B, 4)
+        O.g1_forward(sd1, cfg, x0, *conds, torch.zeros(B, dtype=torch.int64), zs[0])
+
+    cpu_model = platform.processor() or ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), cpu_model)
+    except OSError:
+        pass
+    n_warm, n_timed = int(os.environ.get('MUDIFF_CPU_WARMUP', '2')), int(os.environ.get('MUDIFF_CPU_SLICES', '3'))
+    with torch.no_grad():
+        torch.set_num_threads(ncores)
+        for i in range(n_warm):
+            run(1, 100 + i)
+        times = [run(1, 5 + i) for i in range(n_timed)]
+        out = dict(value=round(n_timed / sum(times), 5), unit='slices/s', cores=ncores, kind='port',
+                   sample=f'{n_timed} slices one at a time (B=1, {T} steps, both generators, 256x256, nf=64) after {n_warm} warm-up slices; '
+                          f'{", ".join(f"{t:.2f}" for t in times)} s; torch {torch.__version__} CPU fp32; {cpu_model}',
+                   s_per_slice=[round(t, 3) for t in times], cpu_model=cpu_model, torch=torch.__version__)
+        if full:
+            warm_forward(8)
+            t8 = run(8, 9)
+            out['b8'] = dict(value=round(8 / t8, 5), unit='slices/s', cores=ncores, sample=f'one batch of 8 after a 1-forward warm-up; {t8:.2f} s')
+            torch.set_num_threads(1)
+            warm_forward(1)
+            t1 = run(1, 5)
+            out['one_thread'] = dict(value=round(1 / t1, 5), unit='slices/s', cores=1, sample=f'1 slice after a 1-forward warm-up; {t1:.2f} s')
+            torch.set_num_threads(ncores)
+    return out
 
 
 def csrc_digest():
@@ -407,11 +483,21 @@ def dryrun_worker(a, rank, world):
         dist.init_process_group(backend='gloo', init_method='env://')
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     lo, hi = shard_range(a.total_slices, rank, world) if a.total_slices else (rank * a.batch, (rank + 1) * a.batch)
+    bcast = per_rank = None
     if world > 1:
+        torch.manual_seed(rank)                               # ranks start with DIFFERENT parameters; rank 0's must win
+        mods = [torch.nn.Linear(8, 4), torch.nn.Linear(4, 2)]
+        bcast = timed_broadcast(mods, 'cpu')
+        ref = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(ref, sum(p.double().sum() for m in mods for p in m.parameters()).float().reshape(1))
+        assert all(torch.equal(r, ref[0]) for r in ref), 'parameters differ between ranks after the broadcast'
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
-    dt = max_over_ranks(time.perf_counter() - t0, 'cpu')
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, 'cpu')
+    if world > 1:
+        per_rank = per_rank_rates(hi - lo, dt_local, 'cpu', world)
     seen = [None] * world
     if world > 1:
         dist.all_gather_object(seen, (rank, lo, hi))
@@ -420,7 +506,8 @@ def dryrun_worker(a, rank, world):
     if rank == 0:
         print(json.dumps({'metric': METRIC, 'dryrun': True, 'n_gpus': world, 'ranks_seen': sorted(s[0] for s in seen),
                           'shards': [list(s[1:]) for s in sorted(seen)], 'value': round((a.total_slices or world * a.batch) / dt, 3),
-                          'ms_per_step': round(1e3 * dt, 3), 'scaling': 'strong' if a.total_slices else 'weak'}), flush=True)
+                          'ms_per_step': round(1e3 * dt, 3), 'scaling': 'strong' if a.total_slices else 'weak',
+                          **({'per_rank': per_rank, 'param_broadcast': bcast} if world > 1 else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -459,7 +546,7 @@ def worker(a):
     cfg = bench_config()
     B, K, W = a.batch, a.steps, a.warmup
     H = cfg.image_size
-    g1, g2 = build_models(cfg, dev, rank, world)
+    g1, g2, bcast = build_models(cfg, dev, rank, world)
     coef = S.Posterior_Coefficients(cfg, dev)
     strong = a.total_slices > 0
     if strong:
@@ -506,14 +593,17 @@ def worker(a):
     for _ in range(K):
         out = one_step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     assert out is None or torch.isfinite(out).all()
     dt = max_over_ranks(dt, dev)
+    per_rank = per_rank_rates(n_local * K, dt_local, dev, world) if world > 1 else None
 
     slices = (a.total_slices if strong else world * B) * K
     value = slices / dt
     log(f'timed region: {dt:.3f} s for {slices} slices -> {value:.2f} slices/s')
-    workload = (f'BASELINE config 2 shapes: 4-step dual-generator sampling, 256x256, nf=64, ch_mult 1-2-4, '
+    which = 'BASELINE config 3 (BraTS-shaped test-split batches of 32; model and slice shapes of config 2)' if B == 32 else \
+            ('BASELINE config 2 read literally (one slice at a time)' if B == 1 else 'BASELINE config 2 shapes')
+    workload = (f'{which}: 4-step dual-generator sampling, 256x256, nf=64, ch_mult 1-2-4, '
                 + (f'{a.total_slices} slices per step sharded contiguously over {world} GPU(s) in batches of {B}'
                    if strong else f'{B} slices per GPU per step, batch-sharded over {world} GPU(s)') + ', weights replicated')
     line = {
@@ -522,6 +612,7 @@ def worker(a):
         'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32 (convs/attention: bf16 hi+lo split MFMA x3, fp32 accumulate)',
         'data': 'synthetic', 'ranks_seen': ranks_seen,
+        **({'per_rank': per_rank, 'param_broadcast': bcast} if world > 1 else {}),
         'config': {'workload': workload, 'slices_per_gpu_per_step': n_local, 'batch': B, 'hipgraph': not a.no_graph,
                    **({'total_slices': a.total_slices} if strong else {})},
     }
@@ -570,7 +661,7 @@ def worker(a):
         line['pcie_inclusive'] = {'slices_per_s': round(3 * B / tp, 2), 'note': 'pinned host buffers; 3 x H2D + sample + D2H per batch inside the timed region'}
         del sampler
         # latency case of BASELINE config 2 read literally (batch = 1) and config 3's batch of 32, same path, own hipGraphs
-        for nb_, key, iters in ((1, 'batch1', 6), (32, 'batch32', 3)):
+        for nb_, key, iters in ((1, 'batch1', 20), (16, 'batch16', 5), (32, 'batch32', 3)):
             if nb_ == B:
                 line[key] = {'slices_per_s': line['value'], 'note': 'the headline run'}
                 continue
@@ -579,13 +670,14 @@ def worker(a):
             xb = torch.randn(nb_, 1, H, H, device=dev)
             fn = lambda: sb.sample(cs[0], cs[1], cs[2], xb, cfg.num_timesteps)    # noqa: E731
             fn(); fn()
-            line[key] = {'slices_per_s': round(iters * nb_ / timed_batches(fn, iters), 2), 'note': f'same path, {nb_} slice(s) per step'}
+            line[key] = {'slices_per_s': round(iters * nb_ / timed_batches(fn, iters), 2), 'timed_batches': iters,
+                         'note': f'same path, {nb_} slice(s) per step' + (' (BASELINE config 2 read literally)' if nb_ == 1 else '')}
             del sb, cs, xb
         log('parity leg: config 2 fixture through the captured sampler ...')
         line['parity'] = parity_leg(cfg, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        log('timing the CPU oracle on one slice ...')
-        line['cpu_baseline'] = cpu_baseline(cfg)
+        log('timing the CPU oracle (2 warm-up + 3 timed slices, all cores' + (', then B=8 and 1 thread' if a.cpu_baseline_full else '') + ') ...')
+        line['cpu_baseline'] = cpu_baseline(cfg, full=a.cpu_baseline_full)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

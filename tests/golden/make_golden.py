@@ -413,6 +413,36 @@ def golden_cfg3():
     return out
 
 
+CFG3_MODS = ['FLAIR', 'T2', 'T1', 'T1CE']        # channel order of brats_like_slices_u8's 4 synthetic contrasts
+CFG3_ORDERS = {      # reference dataset/dataset_brats.py:29-34: condition order per target contrast (target last)
+    'T1CE': ['FLAIR', 'T2', 'T1', 'T1CE'],
+    'FLAIR': ['T1CE', 'T1', 'T2', 'FLAIR'],
+    'T2': ['T1CE', 'T1', 'FLAIR', 'T2'],
+    'T1': ['FLAIR', 'T1CE', 'T2', 'T1'],
+}
+
+
+def golden_cfg3_wide():
+    """BASELINE config 3 as SURVEY.md section 8(d) item 3 words it: a BraTS-shaped test split over ALL FOUR target contrasts.
+    16 distinct synthetic slices, 4 per target ordering; the reference samples each group as one B=4 batch (its own
+    sample_from_model, bit-checked against the replay), every step's x_new is stored."""
+    print('config 3 (wide): 16 distinct BraTS-shaped slices, 4 per target ordering, 4 steps each (takes ~10 min)')
+    cfg = O.default_config()
+    u8 = brats_like_slices_u8(16, seed=2020)
+    sl = torch.from_numpy(u8.astype(np.float32)) / 255.0 * 2.0 - 1.0
+    out = {'slices_u8': u8, 'targets': np.array(list(CFG3_ORDERS))}
+    for gi, (tgt, order) in enumerate(CFG3_ORDERS.items()):
+        idx = slice(4 * gi, 4 * gi + 4)
+        conds = [sl[idx, CFG3_MODS.index(m)][:, None].contiguous() for m in order[:3]]
+        x_init, zs, noises, steps, o_steps = run_sampler(cfg, 1234, 314 + gi, conds, 4)
+        for k, (r, o) in enumerate(zip(steps, o_steps)):
+            for nm, a, b in zip(('x01', 'x02', 'xnew'), o, r):
+                check(f'cfg3w.{tgt}.step{k}.{nm}', a, b, 5e-5)
+            out[f'{tgt}.step{k}.xnew'] = r[2].numpy().astype(np.float32)
+        print(f'    cfg3w {tgt}: final range [{float(steps[-1][2].min()):.3f},{float(steps[-1][2].max()):.3f}]', flush=True)
+    return out
+
+
 CFG5 = dict(ch_mult=[1, 1, 2, 2, 4], num_timesteps=8, attn_resolutions=(16,))   # BASELINE config 5 (SURVEY.md section 8d, item 5)
 
 
@@ -587,6 +617,7 @@ def main():
     ap.add_argument('--skip-full', action='store_true')
     ap.add_argument('--only-cfg5', action='store_true', help='(re)generate full_cfg5.npz alone')
     ap.add_argument('--only-cfg3', action='store_true', help='(re)generate batch_cfg3.npz alone')
+    ap.add_argument('--only-cfg3-wide', action='store_true', help='(re)generate wide_cfg3.npz alone')
     ap.add_argument('--only-volume', action='store_true', help='(re)generate volume.npz alone')
     ap.add_argument('--only-variants', action='store_true', help='(re)generate variants.npz alone')
     a = ap.parse_args()
@@ -596,6 +627,12 @@ def main():
         if not a.check:
             np.savez_compressed(os.path.join(HERE, 'batch_cfg3.npz'), **d)
             print('wrote batch_cfg3.npz', f'{os.path.getsize(os.path.join(HERE, "batch_cfg3.npz")) / 1e6:.2f} MB')
+        return
+    if a.only_cfg3_wide:
+        d = golden_cfg3_wide()
+        if not a.check:
+            np.savez_compressed(os.path.join(HERE, 'wide_cfg3.npz'), **d)
+            print('wrote wide_cfg3.npz', f'{os.path.getsize(os.path.join(HERE, "wide_cfg3.npz")) / 1e6:.2f} MB')
         return
     if a.only_variants:
         d = t2n(golden_variants())
@@ -631,6 +668,7 @@ def main():
         files['full_cfg2.npz'] = full
         files['full_cfg5.npz'] = golden_cfg5()
         files['batch_cfg3.npz'] = golden_cfg3()
+        files['wide_cfg3.npz'] = golden_cfg3_wide()
     worst = max(REPORT, key=lambda r: r[1])
     print(f'{len(REPORT)} comparisons, worst: {worst[0]} {worst[1]:.3e}')
     if not a.check:

@@ -32,6 +32,12 @@ def test_gpus_2_spawns_two_ranks_and_reports_n_gpus_2():
     d = _line(p)
     assert d['n_gpus'] == 2 and d['ranks_seen'] == [0, 1] and d['scaling'] == 'weak'
     assert d['ms_per_step'] >= 20.0          # MAX over ranks: rank 1's stand-in region is the longer one (2 x 10 ms)
+    # N-rank reporting (north_star: "RCCL broadcast of params ... at load only"; reference engine/train.py:188-190): every rank's
+    # own rate next to the MAX-over-ranks headline, and the load-time broadcast in bytes / ms (the dry run broadcasts two
+    # small Linear modules over gloo and asserts that rank 0's parameters arrived everywhere)
+    pr, pb = d['per_rank'], d['param_broadcast']
+    assert len(pr['slices_per_s']) == 2 and pr['min'] <= pr['max'] and pr['slices_per_s'][1] < pr['slices_per_s'][0]
+    assert pb['bytes'] == 4 * (8 * 4 + 4 + 4 * 2 + 2) and pb['messages'] == 2 and pb['ms'] > 0
 
 
 def test_strong_scaling_shards_cover_the_total_once():
@@ -65,6 +71,36 @@ def test_sweep_prints_one_line_with_the_counts_that_fit():
     d = _line(p)
     assert sorted(d['slices_per_s_by_gpus']) == ['1', '2'] and d['skipped_gpu_counts'] == [4] and d['scaling'] == 'strong'
     assert d['ranks_seen_by_gpus'] == {'1': [0], '2': [0, 1]} and d['total_slices'] == 24
+    assert set(d['efficiency_vs_1gpu']) == {'1', '2'} and d['efficiency_vs_1gpu']['1'] == 1.0
+    assert list(d['per_rank_by_gpus']) == ['2'] and d['param_broadcast_by_gpus']['2']['messages'] == 2
+
+
+def test_sweep_whose_first_count_does_not_fit_still_carries_the_extras():
+    """--sweep 8,2,1 on a 2-GPU box used to pass --no-cpu-baseline / --no-roofline to every run that executed
+    (they rode on counts[0] only); now they ride on the first count that actually runs."""
+    sys.path.insert(0, REPO)
+    import bench
+    calls = []
+
+    def fake_launch(n, args, **kw):
+        calls.append((n, list(args)))
+        return 0, json.dumps({'value': 10.0 * n, 'ms_per_step': 1.0, 'ranks_seen': list(range(n)), 'cpu_baseline': {'value': 0.1} if '--no-cpu-baseline' not in args else None,
+                              'roofline': {'frac': 0.1} if '--no-roofline' not in args else None})
+    old = bench.launch_ranks, bench.visible_gpus
+    bench.launch_ranks, bench.visible_gpus = fake_launch, (lambda: 4)
+    try:
+        import contextlib
+        import io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rc = bench.run_sweep(bench.parse(['--sweep', '8,4,2']), ['--sweep', '8,4,2'])
+    finally:
+        bench.launch_ranks, bench.visible_gpus = old
+    d = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert rc == 0 and d['skipped_gpu_counts'] == [8] and [c[0] for c in calls] == [4, 2]
+    assert '--no-cpu-baseline' not in calls[0][1] and '--no-roofline' not in calls[0][1]
+    assert '--no-cpu-baseline' in calls[1][1] and '--no-roofline' in calls[1][1]
+    assert d['cpu_baseline'] == {'value': 0.1} and d['roofline'] == {'frac': 0.1} and d['efficiency_vs_1gpu'] is None
 
 
 def test_launcher_helpers():
@@ -74,7 +110,7 @@ def test_launcher_helpers():
     assert bench.last_json_line('nothing here') is None
     assert len(bench.csrc_digest()) == 16
     a = bench.parse(['--gpus', '4', '--total-slices', '512'])
-    assert a.gpus == 4 and a.total_slices == 512 and a.batch == 16
+    assert a.gpus == 4 and a.total_slices == 512 and a.batch == 32      # default batch = BASELINE config 3
 
 
 @pytest.mark.parametrize('which', ['g1', 'g2'])
@@ -106,3 +142,6 @@ def test_two_real_ranks_on_the_gpu_box():
         d = _line(p)
         assert d['n_gpus'] == 2 and d['ranks_seen'] == [0, 1] and d['scaling'] == scaling and d['value'] > 0
         assert d['config']['hipgraph'] is True
+        # the generators' parameters: 20,472,065 (G1) + 21,399,681 (G2) fp32 values in two flattened messages
+        assert d['param_broadcast']['bytes'] == 4 * (20472065 + 21399681) and d['param_broadcast']['messages'] == 2
+        assert len(d['per_rank']['slices_per_s']) == 2 and 0 < d['per_rank']['min'] <= d['per_rank']['max']
