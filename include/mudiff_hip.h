@@ -42,8 +42,16 @@ extern "C" {
 #define MUD_PRO_AFFINE_SILU 2  /* silu(a[b,c]*x + s[b,c])      (AdaGN + SiLU of the ResBlock) */
 #define MUD_PRO_LRELU 3        /* lrelu_0.2(x), no affine      (DownConvBlock of the critic)  */
 
+/* arithmetic plan of one mud_conv2d_mfma launch (mud_conv_args.prec); the weights must have been packed for the same plan */
+#define MUD_PREC_16X3 0        /* every product as hi*hi + hi*lo + lo*hi on the 16-bit MFMA (bf16 pieces): ~2^-17 per product */
+#define MUD_PREC_FP8X 1        /* hi*hi on the fp16 MFMA + both cross terms on the block-scaled e4m3 MFMA: ~2^-15 per product, */
+                               /* 0.78x the matrix cycles; 3x3 launches that fill the chip (mud_conv2d_mfma_prec_supported)     */
+
 int mud_version(void);
 const char* mud_last_error(void);
+/* "" for the shipped build; an experiment build (scripts/build_variants.py) reports the -D flags it was compiled with, so that a
+ * library can always be asked what it is (mudiff_hip.load() refuses anything else unless MUDIFF_ALLOW_VARIANT=1). */
+const char* mud_build_flags(void);
 /* bytes of device workspace the calls below need at most for a given problem: see each call */
 
 /* ---- L3: Gaussian posterior / forward diffusion (engine/test.py:126-177, engine/train.py:256-281)
@@ -152,6 +160,9 @@ typedef struct mud_conv_args {
   /* (layerspp.py:320-321, x = Conv_2(x)) produced by the same launch: skip_out[pixel, co] = sum_ci x[pixel, ci] * skip_w + bias. */
   /* skip_w: mud_pack_weights(ks = 1) of the [Cout, Cin] matrix; x is then read from HBM once instead of twice.  Cin <= 512.      */
   const void* skip_w; const float* skip_bias; float* skip_out; int skip_ldo;
+  /* mud_conv2d_mfma - arithmetic plan of this launch (MUD_PREC_*; 0 = the default) and, for MUD_PREC_FP8X, the power-of-two         */
+  /* exponent the weights' e4m3 image was packed with (mud_pack_weights_prec: the largest e with max|w| * 2^e <= 448).               */
+  int prec; int w_exp;
 } mud_conv_args;
 
 /* Exact fp32 direct convolution (FMA chain per output), any ks/stride/pad/Cin/Cout.
@@ -169,7 +180,13 @@ int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout);
  *   K^T of attention: rows of K as "co": s_ci=1, s_co=ldk;   V: s_ci=ldv, s_co=1.               */
 int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride,
                      int ks, int Cin, int Cout, int nbatch, void* dst, void* stream);
+/* The same for a given arithmetic plan: MUD_PREC_FP8X (ks == 3 only) writes fp16 hi planes and the two e4m3 images
+ * (w * 2^w_exp, (w - fp16(w)) * 2^(w_exp + 11)) in place of the lo planes; same size. */
+int mud_pack_weights_prec(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride,
+                          int ks, int Cin, int Cout, int nbatch, int prec, int w_exp, void* dst, void* stream);
 int mud_conv2d_mfma(const mud_conv_args* a, void* stream);
+/* 1 when mud_conv2d_mfma has plan `prec` for this launch (sizes, prologue mode, skip_w, sub2 are looked at), else 0. */
+int mud_conv2d_mfma_prec_supported(const mud_conv_args* a, int prec);
 /* Bytes of split-K workspace mud_conv2d_mfma would use for this call (0: the launch is not split). */
 int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* a);
 

@@ -68,7 +68,11 @@ class _Prepared:
 class ConvParam:
     """A conv weight prepared for one of the two kernels."""
 
-    def __init__(self, conv: nn.Conv2d):
+    def __init__(self, conv: nn.Conv2d = None, weight=None, bias=None):
+        """conv: an nn.Conv2d; or weight [O,I,k,k] (+ bias) of a stride-1 'same' convolution (several convs merged into one)."""
+        if conv is None:
+            from types import SimpleNamespace
+            conv = SimpleNamespace(weight=weight, bias=bias, stride=(1, 1), padding=(weight.shape[2] // 2,) * 2)
         w = conv.weight.detach()
         self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
         # C_out <= 4 3x3 convs (the image-space output / pyramid convs) have a dedicated exact kernel on the direct path
@@ -76,8 +80,24 @@ class ConvParam:
         self.mfma = use_mfma(self.cin, self.cout) and self.ks in (1, 3) and not tail
         self.w = ops.pack_conv_weight(w) if self.mfma else ops.direct_weight(w)
         self.bias = conv.bias.detach().contiguous() if conv.bias is not None else None
+        self._w32, self._w8, self.w_exp = w, None, 0       # the fp32 weight stays referenced: other arithmetic plans are packed on first use
+
+    def fp8x(self):
+        """The operand packed for MUD_PREC_FP8X (fp16 hi planes + e4m3 images at this layer's own exponent), made on first use."""
+        if self._w8 is None:
+            self.w_exp = ops.fp8x_weight_exponent(self._w32)
+            self._w8 = ops.pack_conv_weight(self._w32, prec=ops.PREC_FP8X, w_exp=self.w_exp)
+        return self._w8
+
+    def plan(self, x, pro=None, skip=None, sub2=False):
+        """The arithmetic plan this launch would run with (ops.choose_prec)."""
+        if not self.mfma or self.ks != 3:
+            return ops.PREC_16X3
+        return ops.choose_prec(x, self.cout, pro[2] if pro is not None else ops.PRO_NONE, skip=skip is not None, sub2=sub2)
 
     def __call__(self, x, **kw):
+        if self.plan(x, kw.get('pro'), kw.get('skip'), kw.get('sub2', False)) == ops.PREC_FP8X:
+            return ops.conv(x, self.fp8x(), self.ks, self.cout, mfma=True, bias=self.bias, prec=ops.PREC_FP8X, w_exp=self.w_exp, **kw)
         return ops.conv(x, self.w, self.ks, self.cout, mfma=self.mfma, bias=self.bias, **kw)
 
 
@@ -291,6 +311,8 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         else:
             x_skip = x
             fused = 'c2' in p and p['c0'].mfma and p['c2'].mfma and ops.fused_skip_ok(x, self.out_ch, PRO_AFFINE_SILU)
+            if fused and p['c0'].plan(x, (sc0, sh0, PRO_AFFINE_SILU)) == ops.PREC_FP8X:
+                fused = False      # the cheaper-cross-term plan has no fused-skip form: Conv_0 takes it and Conv_2 is its own (HBM-bound) launch
             if fused:       # Conv_0 and the 1x1 skip Conv_2 read the same x: one launch stages it once and writes both
                 x_skip = View.empty(x.B, x.H, x.W, self.out_ch, x.device)
                 h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena, skip=(p['c2'].w, p['c2'].bias, x_skip))

@@ -242,9 +242,7 @@ class _NCSNppBase(nn.Module, layerspp._Prepared):
             # the att2 gates - so the concatenated condition features are staged once
             gates = [getattr(self, 'feat_att1_' + pair) for pair in self._pairs] + [getattr(self, 'feat_att2_' + pair) for pair in self._pairs]
             wg = torch.cat([g.weight for g in gates], 0).contiguous()              # [2*n_pairs*nf, n_cond*nf, 3, 3]
-            p['g_mfma'] = layerspp.use_mfma(wg.shape[1], wg.shape[0])
-            p['g_w'] = ops.pack_conv_weight(wg) if p['g_mfma'] else ops.direct_weight(wg)
-            p['g_b'] = torch.cat([g.bias for g in gates], 0).contiguous()
+            p['gates'] = layerspp.ConvParam(weight=wg, bias=torch.cat([g.bias for g in gates], 0).contiguous())
             p['fw'] = [layerspp.ConvParam(getattr(self, f'feat_weight_c{j + 1}')) for j in range(len(self._pairs))]
             ada = [mods[e['idx']] for e in self._plan if e['kind'] == 'ada']
             p['ada_w'] = torch.cat([m.group_norm.style.weight for m in ada], 0).contiguous()
@@ -493,8 +491,7 @@ class _G2(_NCSNppBase):
             # att1 gates already multiplied by the feature they gate: sigmoid(conv(cat)) * c_i (pair k gates c_k: c12 -> c1,
             # c23 -> c2, c31 -> c3, reference :778,783,787); att2 gates: plain sigmoid
             npair = len(self._pairs)
-            gall = ops.conv(cat, p['g_w'], 3, 2 * npair * nf, mfma=p['g_mfma'], bias=p['g_b'], act=ACT_SIGMOID,
-                            emul=cat.slice(0, npair * nf), emul_cout=npair * nf)
+            gall = p['gates'](cat, act=ACT_SIGMOID, emul=cat.slice(0, npair * nf), emul_cout=npair * nf)
             gated, g2all = gall.slice(0, npair * nf), gall.slice(npair * nf, npair * nf)
             for j in range(npair):      # fused_ij = g2 * conv(g1 * c_i) + (1 - g2) * c_j   (reference :779-788)
                 other = (j + 1) % nc

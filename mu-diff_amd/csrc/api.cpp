@@ -12,4 +12,10 @@ extern "C" void mud_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* mud_last_error(void) { return g_err; }
-extern "C" int mud_version(void) { return 100; }
+extern "C" int mud_version(void) { return 110; }
+// The shipped build carries no experiment flags; scripts/build_variants.py compiles every translation unit of a variant with
+// -DMUD_BUILD_FLAGS="\"...\"" so that a library can always be asked what it is.
+#ifndef MUD_BUILD_FLAGS
+#define MUD_BUILD_FLAGS ""
+#endif
+extern "C" const char* mud_build_flags(void) { return MUD_BUILD_FLAGS; }

@@ -35,14 +35,33 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#ifndef CM_FP8X
-#define CM_FP8X 0                // EXPERIMENT, 3x3 kernel only: fp16 hi.hi per tap + the two cross terms of a 3-tap
-#endif                           // group as two block-scaled e4m3 MFMAs (K = 3 taps + a zero tap, x 16 channels).  Same LDS images and weight steps:
-                                 // pixel record [f16 hi 32 B][e4m3 a*2^2 16 B][e4m3 a_lo*2^14 16 B], weight step [f16 hi 2 KiB][e4m3 w*2^7 1 KiB][e4m3 w_lo*2^19 1 KiB]
-#define CM_X_SA 2                // constant power-of-two pre-scales of the e4m3 images (undone by the MFMA's E8M0 scale operands)
-#define CM_X_SAL 14
-#define CM_X_SW 7
-#define CM_X_SWL 19
+
+// ---- arithmetic plans of a launch (mud_conv_args.prec)
+//   MUD_PREC_16X3  every product as lo*hi + hi*lo + hi*hi on the 16-bit MFMA (3 x v_mfma_f32_32x32x16): the two 16-bit pieces
+//                  of an fp32 operand are h16 = bf16 (8-bit pieces, fp32's exponent range; ~2^-17 per product).
+//   MUD_PREC_FP8X  hi*hi on the fp16 MFMA (11-bit pieces) + the two cross terms of a 3-tap group as TWO block-scaled e4m3 MFMAs
+//                  (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = (3 taps + a zero tap) x 16 channels, 2x the 16-bit rate):
+//                  288 -> 224 matrix cycles per 3-tap group and accumulator.  The cross terms carry 2^-11 of a product, so 4
+//                  significant bits per operand keep the total at ~2^-15.  3x3 kernel only; same LDS images and weight steps:
+//                  pixel record [f16 hi 32 B][e4m3 a*2^SA 16 B][e4m3 a_lo*2^SAL 16 B][16 B zero = the zero tap],
+//                  weight step  [f16 hi 2 KiB][e4m3 w*2^w_exp 1 KiB][e4m3 w_lo*2^(w_exp+11) 1 KiB]  (w_exp: per layer, chosen at pack time).
+typedef __bf16 h16;                                   // the 16-bit piece type of MUD_PREC_16X3
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 cm_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 cm_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// v = hi + lo (+ ~2^-2p |v|), both pieces in the 16-bit type of V4; fp16 pieces saturate at +-65504 instead of overflowing to inf
+template <typename V4>
+__device__ __forceinline__ void cm_split4(f32x4 v, V4& hi, V4& lo) {
+  if constexpr (std::is_same<V4, f16x4>::value) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+  }
+  hi = __builtin_convertvector(v, V4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), V4);
+}
+#define CM_X_SA 2                // constant power-of-two pre-scales of the e4m3 activation images (undone by the MFMA's E8M0 scale operands):
+#define CM_X_SAL 13              // a*2^2 covers |a| in [5e-4, 112]; a_lo <= 2^-11 |a| -> a_lo*2^13 <= 448 as well.  Out-of-range values only lose their cross term
 __device__ __forceinline__ int cm_e4m3x4(f32x4 v, float scale) {    // 4 floats * scale -> 4 packed OCP e4m3 bytes (hardware converter)
   // v_cvt_pk_fp8_f32 does NOT saturate: |x| >= 480 comes out as NaN (scripts/mfma_f8_layout.hip), so out-of-range values are clamped to +-448 first
   v = v * scale;
@@ -51,27 +70,6 @@ __device__ __forceinline__ int cm_e4m3x4(f32x4 v, float scale) {    // 4 floats 
   int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
   return __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true);
 }
-#ifndef CM_STAGGER
-#define CM_STAGGER 0             // experiment knobs (scripts/build_variants.py); the shipped values are set here
-#endif
-#ifndef CM_PRIO
-#define CM_PRIO 0
-#endif
-#ifndef CM_ORDER
-#define CM_ORDER 2      // MFMA issue order inside a k16 step: 2 = the two accumulators alternate (same per-accumulator order as 0: bit-identical)
-#endif
-#ifndef CM_FAKE16
-#define CM_FAKE16 0
-#endif
-#ifndef CM_WHATIF
-#define CM_WHATIF 0              // TIMING PROBES (wrong results): 1 = no prologue arithmetic in the staging, 2 = no activation loads,
-#endif                           // 3 = no weight DMA, 4 = no MFMAs, 5 = no staging at all (no loads, no arithmetic, no LDS writes),
-                                 // 6 / 7 / 8 = fragment reads only in the first tap of a 3-tap group: all / A only kept / B only kept
-                                 // 9 / 10 = two / one and a half MFMAs per product instead of three (what cheaper cross terms could buy)
-                                 // 11 = hi.hi per tap + both cross terms as two block-scaled fp8 MFMAs per 3-tap group (the section-9 layout)
-#ifndef CM_PRE_RES_ALL
-#define CM_PRE_RES_ALL 0         // 1: the 4-wave tiles prefetch the residual tile too (experiment)
-#endif
 #define CM_BN 64
 #define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
@@ -168,10 +166,14 @@ struct CmFin {
   unsigned* counters;
 };
 
-template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false>
+template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false, int PREC = MUD_PREC_16X3>
 __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) void k_conv_mfma(mud_conv_args a, int tiles_x, int tiles_per_img, int ntiles, int k16s,
                                                                 unsigned nblocks, int nsplit, int64_t split_stride, CmFin fin) {
   using G = CmGeo<KS, MT, WM, WN, DUAL>;
+  constexpr bool X8 = PREC == MUD_PREC_FP8X;           // fp16 hi.hi + e4m3 cross terms (3x3 only)
+  static_assert(!X8 || KS == 3, "the fp8 cross-term plan is built for the 3x3 kernel");
+  using HV4 = typename std::conditional<X8, f16x4, h16x4>::type;      // 16-bit pieces of the conv's own operands
+  using HV8 = typename std::conditional<X8, f16x8, h16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles
@@ -250,9 +252,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   auto fetch_raw = [&](int chunk) {
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
-#if CM_WHATIF == 2 || CM_WHATIF == 5
-    if (chunk != kc0) return;
-#endif
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
   };
@@ -275,14 +274,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   };
   auto store_a_slots = [&](int chunk, char* buf, int j0, int j1) {
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
-#if CM_WHATIF == 5
-    if (chunk != kc0) return;
-#endif
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
       if (j < j0 || j >= j1) continue;
       f32x4 v = raw[j];
-      if (CM_WHATIF != 1 && (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU)) {
+      if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
         v = v * psc_r + psh_r;
         if (PRO == MUD_PRO_AFFINE_SILU) {
 #pragma unroll
@@ -294,28 +290,24 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
-#if CM_FP8X
-      {
-        const f16x4 hi = __builtin_convertvector(v, f16x4);
-        const f32x4 lo = v - __builtin_convertvector(hi, f32x4);
-        *(f16x4*)(buf + loff[j]) = hi;
-        *(int*)(buf + loff[j] + 32 - q * 4) = cm_e4m3x4(v, (float)(1 << CM_X_SA));         // record + 32 + 4 q   (loff holds record + 8 q)
-        *(int*)(buf + loff[j] + 48 - q * 4) = cm_e4m3x4(lo, (float)(1 << CM_X_SAL));        // record + 48 + 4 q
+      HV4 hi, lo;
+      cm_split4(v, hi, lo);
+      *(HV4*)(buf + loff[j]) = hi;
+      if constexpr (X8) {                       // (loff holds record + 8 q)
+        const f32x4 lof = v - __builtin_convertvector(hi, f32x4);                            // exact in fp32 (|v| <= 65504 here or saturated: see cm_split4)
+        *(int*)(buf + loff[j] + 32 - q * 4) = cm_e4m3x4(v, (float)(1 << CM_X_SA));         // record + 32 + 4 q
+        *(int*)(buf + loff[j] + 48 - q * 4) = cm_e4m3x4(lof, (float)(1 << CM_X_SAL));      // record + 48 + 4 q
+      } else {
+        *(HV4*)(buf + loff[j] + 32) = lo;
       }
-#else
-      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-      const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-      *(bf16x4*)(buf + loff[j]) = hi;
-      *(bf16x4*)(buf + loff[j] + 32) = lo;
-#endif
-      if (DUAL) {                               // the RAW value of the tile's centre pixels: A operand of the 1x1 skip conv
+      if (DUAL) {                               // the RAW value of the tile's centre pixels: A operand of the 1x1 skip conv (always 16-bit x 3)
         if (loff2[j] >= 0) {
           const f32x4 rv = raw[j] * (cvalid ? 1.0f : 0.0f);
-          const bf16x4 rhi = __builtin_convertvector(rv, bf16x4);
-          const bf16x4 rlo = __builtin_convertvector(rv - __builtin_convertvector(rhi, f32x4), bf16x4);
+          h16x4 rhi, rlo;
+          cm_split4(rv, rhi, rlo);
           char* a2 = smem + G::A2_OFF;
-          *(bf16x4*)(a2 + loff2[j]) = rhi;
-          *(bf16x4*)(a2 + (loff2[j] ^ 32)) = rlo;         // unit u -> u ^ 2: the lo half sits two 16-B units away under the same swizzle
+          *(h16x4*)(a2 + loff2[j]) = rhi;
+          *(h16x4*)(a2 + (loff2[j] ^ 32)) = rlo;          // unit u -> u ^ 2: the lo half sits two 16-B units away under the same swizzle
         }
       }
     }
@@ -330,9 +322,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   char* const bring = smem + G::B_OFF;
   auto dma_b = [&](int gg) {                    // group gg -> ring slot gg & 1
     if (gg >= total_groups) return;             // wave-uniform
-#if CM_WHATIF == 3
-    if (gg > kc0 * G::NG + 1) return;
-#endif
     char* dst = bring + (gg & 1) * G::GB;
 #pragma unroll
     for (int j = 0; j < (G::PIECES + WM * WN - 1) / (WM * WN); ++j) {
@@ -358,12 +347,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   };
 
   const int lane_a = ((KS == 3) ? (wm * MT * G::PW + r) : (wm * MT * 32 + r)) * CM_PIX + hh * 16;
-#if CM_FP8X
-  const int xa_lane0 = lane_a - hh * 16 + hh * (2 * CM_PIX);                       // e4m3 operand, first 16 bytes: the record of tap 0 (hh = 0) / tap 2 (hh = 1)
-  const int xa_lane1_t0 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 48);  // second 16 bytes, term 0 (a_lo image at +48): tap 1 / zero padding of tap 2's record
+  // fp8 cross terms: K = 64 = (tap 0, tap 1 | tap 2, zero) x 16 channels of a 3-tap group; lane half hh owns K [32 hh, 32 hh + 32)
+  // (operand map checked by scripts/mfma_f8_layout.hip).  Every address is a per-lane base with the lane-half dependence folded in
+  // + a compile-time offset, like the rest of the loop's LDS reads.
+  const int xa_lane0 = lane_a - hh * 16 + hh * (2 * CM_PIX);                        // e4m3 operand, first 16 bytes: the record of tap 0 (hh = 0) / tap 2 (hh = 1)
+  const int xa_lane1_t0 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 48);  // second 16 bytes, term 0 (a_lo image at +48): tap 1 / the zero padding of tap 2's record
   const int xa_lane1_t1 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 32);  // term 1 (a image at +32)
   const int xb_lane = r * 16 + hh * (2 * CM_BSTEP);
-#endif
+  // E8M0 scale operands (2^(byte - 127), the same in every byte) take the constant pre-scales of the e4m3 images back out
+  const int s_a = (127 - CM_X_SA) * 0x01010101, s_al = (127 - CM_X_SAL) * 0x01010101;
+  const int s_w = (127 - a.w_exp) * 0x01010101, s_wl = (127 - a.w_exp - 11) * 0x01010101;
+
   f32x16 acc[MT][2];
   f32x16 acc2[DUAL ? MT : 1][2];                // DUAL: the 1x1 skip conv of the raw input
 #pragma unroll
@@ -378,18 +372,48 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   const int lane_a2 = ((wm * MT) * 32 + r) * 64 + ((hh ^ ((r >> 2) & 3)) << 4);   // DUAL: this lane's hi unit in the raw centre image (row m adds 32 * 64)
 
   // ---- prologue: chunk 0 into A buffer 0, B group 0 into ring slot 0
-#if CM_FP8X
-  if (q == 0) {      // bytes 64..79 of every pixel record in both A buffers: the zero tap of the cross-term MFMAs (never written again)
+  if constexpr (X8) {
+    if (q == 0) {      // bytes 64..79 of every pixel record in both A buffers: the zero tap of the cross-term MFMAs (never written again)
 #pragma unroll
-    for (int j = 0; j < G::NLOAD; ++j) {
-      *(i32x4*)(smem + loff[j] + 64) = i32x4{0, 0, 0, 0};
-      *(i32x4*)(smem + G::BUF + loff[j] + 64) = i32x4{0, 0, 0, 0};
+      for (int j = 0; j < G::NLOAD; ++j) {
+        *(i32x4*)(smem + loff[j] + 64) = i32x4{0, 0, 0, 0};
+        *(i32x4*)(smem + G::BUF + loff[j] + 64) = i32x4{0, 0, 0, 0};
+      }
     }
   }
-#endif
   dma_b(kc0 * G::NG);
   dma_b2(kc0);
   fetch_raw(kc0);
+
+  const int emul_lim = a.emul_cout > 0 ? a.emul_cout : a.Cout;       // emul covers channels [0, emul_lim)
+  const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
+                   mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
+                   (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
+  const bool slab_mode = KS == 3 && nsplit > 1 && fin.counters != nullptr;    // block-uniform
+  // ---- the residual starts in the accumulators.  The epilogue adds a [pixels x channels] tile of `res` the size of the
+  // accumulators; loaded there its HBM time is paid after the MFMAs (a 128->128 layer at 256x256 ran 12 % longer with a
+  // residual), and a register prefetch a few chunks before the end costs 64 VGPRs.  Instead every accumulator register is
+  // LOADED with its residual element here (accumulator layout: lane = channel, register = pixel -> 128-byte runs per half
+  // wave), behind the first staging loads: the sums come out as res + sum(products), no registers are held and nothing is
+  // left for the epilogue.  (Not with sub2 / split-K slabs / the fused skip conv, which has no residual.)
+  const bool res_in_acc = !DUAL && KS == 3 && a.res != nullptr && !a.sub2 && nsplit == 1;
+  if (res_in_acc) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int co = (nt * WN + wn) * CM_BN + n * 32 + r;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int gy = ty0 + wm * MT + m;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int gx = tx0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+          const bool ok = gy < a.H && gx < a.W && co < a.Cout;
+          acc[m][n][reg] = ok ? a.res[(((int64_t)b * a.H + gy) * a.W + gx) * a.ldr + co] : 0.f;
+        }
+      }
+    }
+  }
+
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
     cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF), gn_c);
     __syncthreads();
@@ -398,91 +422,36 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   store_a(kc0, smem + (kc0 & 1) * G::BUF);
   __syncthreads();
 
-  // ---- residual prefetch: the epilogue adds a [pixels x channels] tile of `res` the size of the accumulators.  Loaded
-  // there, its HBM time is paid after the MFMAs (a 128->128 layer at 256x256 ran 12 % longer with a residual); loaded
-  // into registers a few chunks before the end, it streams in underneath them.  Same lane <-> (pixel, 4 channels) mapping
-  // as the epilogue's vector path.
-  const int emul_lim = a.emul_cout > 0 ? a.emul_cout : a.Cout;       // emul covers channels [0, emul_lim)
-  const bool vec = ((a.Cout | a.ldo | emul_lim | (a.res ? a.ldr : 0) | (a.emul ? a.ld_emul : 0) | (a.egate ? (a.ld_egate | a.ld_eother) : 0)) & 3) == 0 &&
-                   mud_dev_aligned16(a.out) && (!a.res || mud_dev_aligned16(a.res)) && (!a.emul || mud_dev_aligned16(a.emul)) &&
-                   (!a.egate || (mud_dev_aligned16(a.egate) && mud_dev_aligned16(a.eother)));
-  const bool slab_mode = KS == 3 && nsplit > 1 && fin.counters != nullptr;    // block-uniform
-  const bool pre_res = !DUAL && KS == 3 && (CM_PRE_RES_ALL || (WM * WN >= 8 && MT >= 2)) && a.res && vec && !a.sub2 && !slab_mode && !CM_FP8X;      // (the experiment needs the 64 prefetch registers: with them the two-row tiles spill 120-193)      // (DUAL has no residual)
-  f32x4 rpre[2][MT][4];
-  const int kc_pre = nchunks - kc0 > 3 ? nchunks - 3 : kc0;
-  auto prefetch_res = [&]() {
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int co4 = (nt * WN + wn) * CM_BN + n * 32 + (lane & 7) * 4;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int gy = ty0 + wm * MT + m, gx = tx0 + pass * 8 + (lane >> 3);
-          const bool ok = gy < a.H && gx < a.W && co4 < a.Cout;
-          const int64_t opix = ((int64_t)b * a.H + (ok ? gy : 0)) * a.W + (ok ? gx : 0);
-          // no select on the loaded value here: it would make the wave wait for the load in the middle of the K loop (the
-          // compiler placed 16 loads + 16 waits back to back); out-of-range lanes read a clamped address and the epilogue
-          // never uses their value
-          rpre[n][m][pass] = *(const f32x4*)(a.res + opix * a.ldr + (ok ? co4 : 0));
-        }
-    }
-  };
-
-#if CM_STAGGER || CM_PRIO == 1
-  const bool late_half = WM * WN == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;   // waves 4-7 (wave-uniform, scalar)
-#endif
-#if CM_PRIO == 1
-  if (late_half) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every arbitration by age: static priority instead
-#endif
-#if CM_WHATIF >= 6
-  bf16x8 wbh[2] = {}, wbl[2] = {}, wah[MT] = {}, wal[MT] = {};
-#endif
   for (int kc = kc0; kc < nchunks; ++kc) {
     char* cur = smem + (kc & 1) * G::BUF;
     char* nxt = smem + ((kc + 1) & 1) * G::BUF;
     const bool more = kc + 1 < nchunks;
-    if (pre_res && kc == kc_pre) prefetch_res();
 #pragma unroll
     for (int g = 0; g < G::NG; ++g) {
       const int gg = kc * G::NG + g;
       dma_b(gg + 1);                            // next group's weights stream in under this group's MFMAs
       if (g == 0 && more) fetch_a(kc + 1);
       const char* bcur = bring + (gg & 1) * G::GB + wn * G::GB1;
-#if CM_STAGGER
-      // role stagger (8-wave workgroups): the two waves of a SIMD run the same program between the same barriers; left alone
-      // they reach their staging VALU work and their MFMA clusters together.  The second-dispatched half (waves 4-7) converts
-      // its share of chunk k+1 BEFORE the group's MFMAs, the first half AFTER them, so one partner's VALU runs beside the
-      // other's matrix work (MI355X_MICROARCH.md, two waves per SIMD, item 9)
-      constexpr bool kStagger = (WM * WN == 8) && G::NG == 3;
-      const int gj0 = (g == 1) ? 0 : G::NLOAD / 2, gj1 = (g == 1) ? G::NLOAD / 2 : G::NLOAD;
-      if (kStagger && more && g >= 1 && late_half) store_a_slots(kc + 1, nxt, gj0, gj1);
-#else
-      constexpr bool kStagger = false;
-#endif
-#if CM_PRIO == 2
-      __builtin_amdgcn_s_setprio(1);
-#endif
       if (DUAL && g == 0) {
         // skip conv: centre tap on the RAW tile.  Read here, at the head of the chunk: the single-buffered raw image and
         // weight slot are rewritten for chunk k+1 from group 1 on, i.e. behind this group's barrier.
         const char* b2 = smem + G::B2_OFF + wn * CM_BSTEP;
-        bf16x8 bh[2], bl[2];
+        h16x8 bh[2], bl[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          bh[n] = *(const bf16x8*)(b2 + n * 1024 + lane_b);
-          bl[n] = *(const bf16x8*)(b2 + CM_BPLANE + n * 1024 + lane_b);
+          bh[n] = *(const h16x8*)(b2 + n * 1024 + lane_b);
+          bl[n] = *(const h16x8*)(b2 + CM_BPLANE + n * 1024 + lane_b);
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const char* a2 = smem + G::A2_OFF + lane_a2 + m * (32 * 64);
-          const bf16x8 ah = *(const bf16x8*)a2;
-          const bf16x8 al = *(const bf16x8*)((const char*)((uintptr_t)a2 ^ 32));
+          const h16x8 ah = *(const h16x8*)a2;
+          const h16x8 al = *(const h16x8*)((const char*)((uintptr_t)a2 ^ 32));
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc2[m][n], 0, 0, 0);
-            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc2[m][n], 0, 0, 0);
-            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc2[m][n], 0, 0, 0);
+            acc2[m][n] = cm_mfma16(al, bh[n], acc2[m][n]);
+            acc2[m][n] = cm_mfma16(ah, bl[n], acc2[m][n]);
+            acc2[m][n] = cm_mfma16(ah, bh[n], acc2[m][n]);
           }
         }
       }
@@ -494,181 +463,75 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         const int tap = (KS == 3) ? st : 0;
         const int dy = tap / KS, dx = tap % KS;
         if (kc * G::CH + s < k16s) {
-#if CM_WHATIF >= 6
-          // stale-fragment probes: 6 = no fragment reads after the first tap of a group, 7 = no B reads, 8 = no A reads
-          if (sg == 0 || CM_WHATIF == 8) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-              wbh[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + n * 1024 + lane_b);
-              wbl[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
-            }
-          }
-          bf16x8 bh[2] = {wbh[0], wbh[1]}, bl[2] = {wbl[0], wbl[1]};
-#else
-          bf16x8 bh[2], bl[2];
+          HV8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            bh[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + n * 1024 + lane_b);
-            bl[n] = *(const bf16x8*)(bcur + sg * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
+            bh[n] = *(const HV8*)(bcur + sg * CM_BSTEP + n * 1024 + lane_b);
+            if constexpr (!X8) bl[n] = *(const HV8*)(bcur + sg * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
           }
-#endif
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             // lane base (wave row, column r, k half hh) + compile-time (m, tap, s) offset
             const int off = s * G::PLANE + ((KS == 3) ? ((m + dy) * G::PW + dx) : (m * 32)) * CM_PIX;
-#if CM_WHATIF >= 6
-            if (sg == 0 || CM_WHATIF == 7) {
-              wah[m] = *(const bf16x8*)(cur + lane_a + off);
-              wal[m] = *(const bf16x8*)(cur + lane_a + off + 32);
+            const HV8 ah = *(const HV8*)(cur + lane_a + off);
+            if constexpr (X8) {
+              // hi.hi in fp16; the cross terms follow the group's last tap
+              acc[m][0] = cm_mfma16(ah, bh[0], acc[m][0]);
+              acc[m][1] = cm_mfma16(ah, bh[1], acc[m][1]);
+            } else {
+              // term by term, the two accumulators alternate: no back-to-back MFMAs on one accumulator (64->64 layers -2 %, others
+              // +-0: profiles/r02_l_ab_mfma_order.txt); each accumulator adds its terms in the order lo.hi, hi.lo, hi.hi
+              const HV8 al = *(const HV8*)(cur + lane_a + off + 32);
+              acc[m][0] = cm_mfma16(al, bh[0], acc[m][0]);
+              acc[m][1] = cm_mfma16(al, bh[1], acc[m][1]);
+              acc[m][0] = cm_mfma16(ah, bl[0], acc[m][0]);
+              acc[m][1] = cm_mfma16(ah, bl[1], acc[m][1]);
+              acc[m][0] = cm_mfma16(ah, bh[0], acc[m][0]);
+              acc[m][1] = cm_mfma16(ah, bh[1], acc[m][1]);
             }
-            const bf16x8 ah = wah[m], al = wal[m];
-#else
-            const bf16x8 ah = *(const bf16x8*)(cur + lane_a + off);
-            const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
-#endif
-#if CM_ORDER == 1      // A/B knob: consecutive MFMAs share an operand register (ah x4, then al x2; B pairs shared)
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[m][1], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
-#elif CM_FP8X
-            {   // hi.hi in fp16 (the same fragment places as the bf16 hi halves); the cross terms follow the group's last tap
-              const f16x8 ah16 = __builtin_bit_cast(f16x8, ah);
-              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, __builtin_bit_cast(f16x8, bh[0]), acc[m][0], 0, 0, 0);
-              acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, __builtin_bit_cast(f16x8, bh[1]), acc[m][1], 0, 0, 0);
-            }
-#elif CM_WHATIF == 11
-            // TIMING PROBE (wrong results): per tap ONE 16-bit MFMA (hi.hi); behind the group's last tap the two cross terms as two
-            // block-scaled fp8 MFMAs per accumulator (K = 64 = 3 taps + a zero tap, x 16 channels), their 32-byte operands read as
-            // 2 x 16 B from the places the e4m3 images would occupy (today's lo halves) - see the block behind the m loop
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);     // (the per-tap lo reads are dead here, as they would be)
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
-#elif CM_WHATIF == 9 || CM_WHATIF == 10   // TIMING PROBE (wrong results): 2 (9) or 1.5 (10) MFMAs per product, all fragment reads kept
-            asm volatile("" :: "v"(al), "v"(bl[1]));
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
-#if CM_WHATIF == 9
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[m][1], 0, 0, 0);
-#endif
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
-#elif CM_ORDER == 2    // term by term, the two accumulators alternate: no back-to-back MFMAs on one accumulator (64->64 layers -2 %,
-                       // others +-0: profiles/r02_l_ab_mfma_order.txt); each accumulator still adds its terms in the order lo.hi, hi.lo, hi.hi
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], acc[m][1], 0, 0, 0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], acc[m][1], 0, 0, 0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[m][1], 0, 0, 0);
-#else
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-#if CM_FAKE16
-              // TIMING PROBE ONLY (results are wrong): the same operand reads and the same MFMA cycles issued as two
-              // 16x16x32 instructions per 32x32x16 one, to see what the other bf16 MFMA shape is worth in THIS kernel
-              // before re-laying out the operands for it (MI355X_MICROARCH.md, DVFS give-back item 7)
-              f32x4 q[4];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) q[i] = f32x4{acc[m][n][4 * i], acc[m][n][4 * i + 1], acc[m][n][4 * i + 2], acc[m][n][4 * i + 3]};
-              q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], q[0], 0, 0, 0);
-              q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], q[1], 0, 0, 0);
-              q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], q[2], 0, 0, 0);
-              q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], q[3], 0, 0, 0);
-              q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], q[0], 0, 0, 0);
-              q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], q[2], 0, 0, 0);
-#pragma unroll
-              for (int i = 0; i < 16; ++i) acc[m][n][i] = q[i >> 2][i & 3];
-#elif CM_WHATIF == 4
-              asm volatile("" :: "v"(al), "v"(ah), "v"(bh[n]), "v"(bl[n]));      // keep the fragment reads alive
-#else
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
-#endif
-            }
-#endif
           }
-#if CM_FP8X
-          if (KS == 3 && sg == G::GS - 1) {
-            // cross terms of this 3-tap group: K = 64 = (tap 0, tap 1 | tap 2, zero) x 16 channels; lane half hh owns K [32 hh, 32 hh + 32)
-            // (operand map checked by scripts/mfma_f8_layout.hip).  The e4m3 images were pre-scaled by constant powers of two, which the
-            // E8M0 scale operands (2^(byte - 127), the same in every byte) take back out, so both terms add straight into acc.
-            // The zero tap lives on the A side: bytes 64..79 of every pixel record (its padding) are zeroed once per workgroup, and lane
-            // half 1 reads them as its second 16 bytes, so no operand needs a select; its B bytes there are tap 1's (finite e4m3, times 0).
-            constexpr int E_A = 127 - CM_X_SA, E_AL = 127 - CM_X_SAL, E_W = 127 - CM_X_SW, E_WL = 127 - CM_X_SWL;
-            constexpr int S_A = E_A * 0x01010101, S_AL = E_AL * 0x01010101, S_W = E_W * 0x01010101, S_WL = E_WL * 0x01010101;
-            // every address is one of a few per-lane bases (the lane-half dependence folded in, computed before the K loop) + a compile-time
-            // offset, as the rest of the loop's LDS reads are: hh-dependent offsets per (group, term, row) cost ~60 address registers
-            const char* brow = bcur + xb_lane;                                // this lane's 16 input channels of output channel r: tap 0 (hh = 0) / tap 2 (hh = 1)
-            const char* brow1 = bcur + CM_BSTEP + r * 16;                     // tap 1
-            const int o0 = ((g * G::GS) / KS * G::PW + (g * G::GS) % KS) * CM_PIX;      // the group's first tap (taps 3g, 3g+1, 3g+2 are one row: +80, +160 bytes)
+          if constexpr (X8) {
+            if (sg == G::GS - 1) {
+              // cross terms of this 3-tap group.  The zero tap lives on the A side: bytes 64..79 of every pixel record (its padding) are
+              // zeroed once per workgroup, and lane half 1 reads them as its second 16 bytes, so no operand needs a select; its B bytes
+              // there are tap 1's (finite e4m3, times 0).
+              const char* brow = bcur + xb_lane;                                // this lane's 16 input channels of output channel r: tap 0 (hh = 0) / tap 2 (hh = 1)
+              const char* brow1 = bcur + CM_BSTEP + r * 16;                     // tap 1
+              const int o0 = ((g * G::GS) / KS * G::PW + (g * G::GS) % KS) * CM_PIX;      // the group's first tap (taps 3g, 3g+1, 3g+2 are one row: +80, +160 bytes)
 #pragma unroll
-            for (int term = 0; term < 2; ++term) {
-              const int wplane = CM_BPLANE + term * 1024, aoff = term ? 32 : 48;      // term 0: a_lo . w_hi, term 1: a_hi . w_lo
-              const char* pa0 = cur + xa_lane0 + o0 + aoff;                           // first 16 bytes: tap 0 / tap 2
-              const char* pa1 = cur + (term ? xa_lane1_t1 : xa_lane1_t0) + o0;        // second: tap 1 / the record's zero padding
-              i32x8 wq[2];
+              for (int term = 0; term < 2; ++term) {
+                const int wplane = CM_BPLANE + term * 1024, aoff = term ? 32 : 48;      // term 0: a_lo . w_hi, term 1: a_hi . w_lo
+                const char* pa0 = cur + xa_lane0 + o0 + aoff;                           // first 16 bytes: tap 0 / tap 2
+                const char* pa1 = cur + (term ? xa_lane1_t1 : xa_lane1_t0) + o0;        // second: tap 1 / the record's zero padding
+                i32x8 wq[2];
 #pragma unroll
-              for (int n = 0; n < 2; ++n) {
-                const i32x4 q0 = *(const i32x4*)(brow + wplane + n * 512);
-                const i32x4 q1 = *(const i32x4*)(brow1 + wplane + n * 512);
-                wq[n] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-              }
+                for (int n = 0; n < 2; ++n) {
+                  const i32x4 q0 = *(const i32x4*)(brow + wplane + n * 512);
+                  const i32x4 q1 = *(const i32x4*)(brow1 + wplane + n * 512);
+                  wq[n] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                }
 #pragma unroll
-              for (int m = 0; m < MT; ++m) {
-                const i32x4 p0 = *(const i32x4*)(pa0 + m * G::PW * CM_PIX);
-                const i32x4 p1 = *(const i32x4*)(pa1 + m * G::PW * CM_PIX);
-                const i32x8 aq = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                for (int m = 0; m < MT; ++m) {
+                  const i32x4 p0 = *(const i32x4*)(pa0 + m * G::PW * CM_PIX);
+                  const i32x4 p1 = *(const i32x4*)(pa1 + m * G::PW * CM_PIX);
+                  const i32x8 aq = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                  acc[m][n] = term ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, S_A, 0, S_WL)
-                                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, S_AL, 0, S_W);
-              }
-            }
-            // (as compiled by hipcc 7.2 all twelve operand reads of the group are issued ahead of its barrier and the four MFMAs sink below it,
-            //  behind the next weight DMA: 48 registers live across the barrier; __builtin_amdgcn_sched_barrier fences here or between the terms
-            //  do not change the allocation - DESIGN.md section 9 item 5)
-          }
-#elif CM_WHATIF == 11
-          if (KS == 3 && sg == G::GS - 1) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              i32x8 xb[2];
-#pragma unroll
-              for (int n = 0; n < 2; ++n) {
-                const i32x4 q0 = *(const i32x4*)(bcur + c * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
-                const i32x4 q1 = *(const i32x4*)(bcur + (c + 1) * CM_BSTEP + CM_BPLANE + n * 1024 + lane_b);
-                xb[n] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-              }
-#pragma unroll
-              for (int m = 0; m < MT; ++m) {
-                const int t0 = g * G::GS + c, t1 = t0 + 1;
-                const i32x4 p0 = *(const i32x4*)(cur + lane_a + ((m + t0 / KS) * G::PW + t0 % KS) * CM_PIX + 32);
-                const i32x4 p1 = *(const i32x4*)(cur + lane_a + ((m + t1 / KS) * G::PW + t1 % KS) * CM_PIX + 32);
-                const i32x8 xa = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                  acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb[n], acc[m][n], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                  for (int n = 0; n < 2; ++n)
+                    acc[m][n] = term ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, s_a, 0, s_wl)
+                                     : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, s_al, 0, s_w);
+                }
               }
             }
           }
-#endif
         }
         // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),
         // so the conversion VALU work interleaves with matrix work instead of forming one long MFMA-free stretch
-        if (!kStagger && more && G::NG > 1 && st >= G::GS) {
+        if (more && G::NG > 1 && st >= G::GS) {
           constexpr int SPAN = G::STEPS - G::GS;                   // steps available for staging
           const int j0 = ((st - G::GS) * G::NLOAD) / SPAN, j1 = ((st - G::GS + 1) * G::NLOAD) / SPAN;
           store_a_slots(kc + 1, nxt, j0, j1);
         }
       }
-#if CM_PRIO == 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
-#if CM_STAGGER
-      if (kStagger && more && g >= 1 && !late_half) store_a_slots(kc + 1, nxt, gj0, gj1);
-#endif
       if (G::NG == 1 && more) store_a(kc + 1, nxt);
       __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
     }
@@ -785,8 +648,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
           }
           f32x4 v = *(const f32x4*)(ep + prow * EP_LD + col);
           if (valid && co4 < a.Cout) {
-            if (pre_res) v += rpre[n][m][pass];
-            else if (a.res) v += *(const f32x4*)(a.res + opix * a.ldr + co4);
+            if (a.res && !res_in_acc) v += *(const f32x4*)(a.res + opix * a.ldr + co4);
             v *= a.out_scale;
             if (a.act != MUD_ACT_NONE) {
 #pragma unroll
@@ -839,7 +701,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
           }
           if (valid && cok) {
             float v = acc[m][n][reg] + badd;
-            if (a.res) v += a.res[opix * a.ldr + co];
+            if (a.res && !res_in_acc) v += a.res[opix * a.ldr + co];
             v = mud_act_fast(v * a.out_scale, a.act);
             if (a.emul && co < emul_lim) v *= a.emul[opix * a.ld_emul + co];
             if (a.egate) {
@@ -1028,23 +890,23 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
       }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
-      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-      const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-      *(bf16x4*)(buf + loff[j]) = hi;
-      *(bf16x4*)(buf + loff[j] + 32) = lo;
+      h16x4 hi, lo;
+      cm_split4(v, hi, lo);
+      *(h16x4*)(buf + loff[j]) = hi;
+      *(h16x4*)(buf + loff[j] + 32) = lo;
     }
   };
 
   // ---- B fragments: [step ring][n tile][hi|lo]
-  bf16x8 bfr[G::RING][2][2];
+  h16x8 bfr[G::RING][2][2];
   const int total_steps = k16s * G::TAPS;       // global step index = k16 * TAPS + tap
   auto fetch_b = [&](int gstep, int slot) {
     if (gstep >= total_steps) gstep = total_steps - 1;   // harmless re-read past the end
     const char* p = wb + (int64_t)gstep * CM_BSTEP;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      bfr[slot][n][0] = *(const bf16x8*)(p + n * 1024);
-      bfr[slot][n][1] = *(const bf16x8*)(p + CM_BPLANE + n * 1024);
+      bfr[slot][n][0] = *(const h16x8*)(p + n * 1024);
+      bfr[slot][n][1] = *(const h16x8*)(p + CM_BPLANE + n * 1024);
     }
   };
 
@@ -1088,13 +950,13 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
         for (int m = 0; m < MT; ++m) {
           // lane base (wave row, column r, k half hh) + compile-time (m, tap, s) offset
           const int off = s * G::PLANE + ((KS == 3) ? ((m + dy) * G::PW + dx) : (m * 32)) * CM_PIX;
-          const bf16x8 ah = *(const bf16x8*)(cur + lane_a + off);
-          const bf16x8 al = *(const bf16x8*)(cur + lane_a + off + 32);
+          const h16x8 ah = *(const h16x8*)(cur + lane_a + off);
+          const h16x8 al = *(const h16x8*)(cur + lane_a + off + 32);
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[slot][n][0], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[slot][n][1], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[slot][n][0], acc[m][n], 0, 0, 0);
+            acc[m][n] = cm_mfma16(al, bfr[slot][n][0], acc[m][n]);
+            acc[m][n] = cm_mfma16(ah, bfr[slot][n][1], acc[m][n]);
+            acc[m][n] = cm_mfma16(ah, bfr[slot][n][0], acc[m][n]);
           }
         }
       }
@@ -1237,13 +1099,14 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight / B-operand packing: fp32 (arbitrary strides) -> [n tile][k16 chunk][tap][hi|lo][64 co][16 ci] bf16
+// weight / B-operand packing: fp32 (arbitrary strides) -> [n tile][k16 chunk][tap][hi|lo][64 co][16 ci] 16-bit pieces
 // (exactly the order in which a wave's lanes consume MFMA B fragments: lane (r, h) of n-tile n reads the 16 B
-//  at co = 32n + r, ci = 8h..8h+7)
+//  at co = 32n + r, ci = 8h..8h+7).  prec = MUD_PREC_FP8X (3x3 only): the lo plane of a step holds the two e4m3 images
+//  instead: [w * 2^w_exp: [2 n][32 co][16 ci] bytes][w_lo * 2^(w_exp + 11): the same], the hi plane fp16.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ src, int64_t s_tap, int64_t s_ci, int64_t s_co,
                                                       int64_t src_bstride, int taps, int Cin, int Cout, int k16s,
-                                                      int64_t units, char* __restrict__ dst, int64_t dst_bstride) {
+                                                      int64_t units, char* __restrict__ dst, int64_t dst_bstride, int prec, int w_exp) {
   const int b = blockIdx.y;
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (int64_t)gridDim.x * blockDim.x) {
     const int h2 = (int)(u & 1), co_l = (int)((u >> 1) & 63);
@@ -1253,44 +1116,38 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     const int kc = (int)(rest % k16s);
     const int nt = (int)(rest / k16s);
     const int co = nt * CM_BN + co_l, ci0 = kc * 16 + h2 * 8;
-    bf16x8 hi, lo;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = 0.f;
       if (co < Cout && ci0 + j < Cin) v = src[(int64_t)b * src_bstride + tap * s_tap + (int64_t)(ci0 + j) * s_ci + (int64_t)co * s_co];
-      const __bf16 h = (__bf16)v;
-      hi[j] = h;
-      lo[j] = (__bf16)(v - (float)h);
+      if (j < 4) v0[j] = v;
+      else v1[j - 4] = v;
     }
-    char* base = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP + co_l * 32 +
-                 ((h2 ^ ((co_l >> 3) & 1)) << 4);   // 16-B halves swapped on rows with bit 3 set: the image is copied verbatim to LDS
-#if CM_FP8X
-    if (taps == 9) {      // 3x3 operand of the experiment: [f16 hi plane 2 KiB, same places][e4m3 w * 2^7: [2 n][32 co][16 ci]][e4m3 w_lo * 2^19: the same]
-      f16x8 h16;
-      f32x4 w0, w1, l0, l1;
-      float vv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = 0.f;
-        if (co < Cout && ci0 + j < Cin) v = src[(int64_t)b * src_bstride + tap * s_tap + (int64_t)(ci0 + j) * s_ci + (int64_t)co * s_co];
-        vv[j] = v;
-        h16[j] = (_Float16)v;
-      }
-      w0 = f32x4{vv[0], vv[1], vv[2], vv[3]}; w1 = f32x4{vv[4], vv[5], vv[6], vv[7]};
-      l0 = f32x4{vv[0] - (float)h16[0], vv[1] - (float)h16[1], vv[2] - (float)h16[2], vv[3] - (float)h16[3]};
-      l1 = f32x4{vv[4] - (float)h16[4], vv[5] - (float)h16[5], vv[6] - (float)h16[6], vv[7] - (float)h16[7]};
-      *(f16x8*)base = h16;
-      char* step = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP;
+    char* step = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP;
+    char* base = step + co_l * 32 + ((h2 ^ ((co_l >> 3) & 1)) << 4);   // 16-B halves swapped on rows with bit 3 set: the image is copied verbatim to LDS
+    if (prec == MUD_PREC_FP8X) {
+      f16x4 h0, h1, l0, l1;
+      cm_split4(v0, h0, l0);
+      cm_split4(v1, h1, l1);
+      *(f16x4*)base = h0;
+      *(f16x4*)(base + 8) = h1;
+      const f32x4 lf0 = v0 - __builtin_convertvector(h0, f32x4), lf1 = v1 - __builtin_convertvector(h1, f32x4);
+      const float sw = exp2f((float)w_exp), swl = exp2f((float)(w_exp + 11));
       char* row8 = step + CM_BPLANE + (co_l >> 5) * 512 + (co_l & 31) * 16 + h2 * 8;
-      *(int*)(row8) = cm_e4m3x4(w0, (float)(1 << CM_X_SW));
-      *(int*)(row8 + 4) = cm_e4m3x4(w1, (float)(1 << CM_X_SW));
-      *(int*)(row8 + 1024) = cm_e4m3x4(l0, (float)(1 << CM_X_SWL));
-      *(int*)(row8 + 1024 + 4) = cm_e4m3x4(l1, (float)(1 << CM_X_SWL));
-      continue;
+      *(int*)(row8) = cm_e4m3x4(v0, sw);
+      *(int*)(row8 + 4) = cm_e4m3x4(v1, sw);
+      *(int*)(row8 + 1024) = cm_e4m3x4(lf0, swl);
+      *(int*)(row8 + 1024 + 4) = cm_e4m3x4(lf1, swl);
+    } else {
+      h16x4 h0, h1, l0, l1;
+      cm_split4(v0, h0, l0);
+      cm_split4(v1, h1, l1);
+      *(h16x4*)base = h0;
+      *(h16x4*)(base + 8) = h1;
+      *(h16x4*)(base + CM_BPLANE) = l0;
+      *(h16x4*)(base + CM_BPLANE + 8) = l1;
     }
-#endif
-    *(bf16x8*)base = hi;
-    *(bf16x8*)(base + CM_BPLANE) = lo;
   }
 }
 
@@ -1299,19 +1156,26 @@ extern "C" int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout) {
   return mud_cdiv(Cout, CM_BN) * mud_cdiv(Cin, 16) * (int64_t)ks * ks * CM_BSTEP + 2 * CM_BSTEP;   // + slack: the last DMA group of a 1x1 operand with an odd number of 16-channel chunks reads one step past the end
 }
 
-extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride, int ks,
-                                int Cin, int Cout, int nbatch, void* dst, void* stream) {
+extern "C" int mud_pack_weights_prec(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride, int ks,
+                                     int Cin, int Cout, int nbatch, int prec, int w_exp, void* dst, void* stream) {
   MUD_REQUIRE(src && dst, "mud_pack_weights: null pointer");
   MUD_REQUIRE((ks == 1 || ks == 3) && Cin > 0 && Cout > 0 && nbatch >= 1 && nbatch <= 65535, "mud_pack_weights: bad sizes");
   MUD_REQUIRE(mud_aligned16(dst), "mud_pack_weights: dst must be 16-byte aligned");
+  MUD_REQUIRE(prec == MUD_PREC_16X3 || (prec == MUD_PREC_FP8X && ks == 3 && w_exp >= -100 && w_exp <= 100),
+              "mud_pack_weights: prec must be MUD_PREC_16X3, or MUD_PREC_FP8X with ks == 3 and |w_exp| <= 100 (got prec=%d ks=%d w_exp=%d)", prec, ks, w_exp);
   const int k16s = (int)mud_cdiv(Cin, 16), ntiles = (int)mud_cdiv(Cout, CM_BN), taps = ks * ks;
   const int64_t units = (int64_t)ntiles * k16s * taps * 128;
   int64_t blocks = mud_cdiv(units, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(k_pack_weights, dim3((int)blocks, nbatch), dim3(256), 0, (hipStream_t)stream, src, s_tap, s_ci, s_co,
-                     src_bstride, taps, Cin, Cout, k16s, units, (char*)dst, mud_packed_weight_bytes(ks, Cin, Cout));
+                     src_bstride, taps, Cin, Cout, k16s, units, (char*)dst, mud_packed_weight_bytes(ks, Cin, Cout), prec, w_exp);
   MUD_CHECK_LAUNCH("mud_pack_weights");
   return MUD_OK;
+}
+
+extern "C" int mud_pack_weights(const float* src, int64_t s_tap, int64_t s_ci, int64_t s_co, int64_t src_bstride, int ks,
+                                int Cin, int Cout, int nbatch, void* dst, void* stream) {
+  return mud_pack_weights_prec(src, s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch, MUD_PREC_16X3, 0, dst, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1400,11 +1264,11 @@ static int cm_splits(int64_t blocks, int nchunks) {
   return ns;
 }
 
-template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false>
+template <int KS, int MT, int WM, int WN, int PRO, bool DUAL = false, int PREC = MUD_PREC_16X3>
 static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
   using G = typename std::conditional<KS == 3, CmGeo<KS, MT, WM, WN, DUAL>, CmGeoRegB<KS, MT>>::type;
   const void* kfn;
-  if constexpr (KS == 3) kfn = (const void*)k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>;      // only the variant that is launched is instantiated
+  if constexpr (KS == 3) kfn = (const void*)k_conv_mfma<KS, MT, WM, WN, PRO, DUAL, PREC>;      // only the variant that is launched is instantiated
   else kfn = (const void*)k_conv_mfma_regb<KS, MT, PRO>;
   static mud_attr_once attr_once;
   if (attr_once.need()) {
@@ -1446,12 +1310,12 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       const int64_t stride = npix * a.Cout;
       // with arrival counters (one per output tile, zero between launches) the last workgroup of each tile reduces the slabs itself
       if (in_launch) {
-        hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, a, tiles_x,
+        hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL, PREC>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, a, tiles_x,
                            (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, (int64_t)0, CmFin{(float*)a.splitk_ws, a.splitk_counters});
         MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K, reduced in the launch)");
         return MUD_OK;
       }
-      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, p, tiles_x,
+      hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL, PREC>), dim3((unsigned)(nblocks * ns)), dim3(64 * WM * WN), lds, s, p, tiles_x,
                          (int)tiles, ntiles, k16s, (unsigned)(nblocks * ns), ns, stride, CmFin{nullptr, nullptr});
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K)");
       const int64_t HW = (int64_t)a.H * a.W;
@@ -1462,7 +1326,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       MUD_CHECK_LAUNCH("mud_conv2d_mfma(split-K epilogue)");
       return MUD_OK;
     }
-    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL>), dim3((unsigned)nblocks), dim3(64 * WM * WN), lds, s, a, tiles_x, (int)tiles,
+    hipLaunchKernelGGL((k_conv_mfma<KS, MT, WM, WN, PRO, DUAL, PREC>), dim3((unsigned)nblocks), dim3(64 * WM * WN), lds, s, a, tiles_x, (int)tiles,
                        ntiles, k16s, (unsigned)nblocks, 1, (int64_t)0, CmFin{nullptr, nullptr});
   } else
     hipLaunchKernelGGL((k_conv_mfma_regb<KS, MT, PRO>), dim3((unsigned)nblocks), dim3(256), lds, s, a, tiles_x, (int)tiles, ntiles, k16s,
@@ -1502,7 +1366,7 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
   // 79 KiB of LDS and 110 VGPRs, so two workgroups share a CU (four waves per SIMD) and one's residual / store phase runs
   // under the other's K loop.  Measured against the 16-row tile (profiles/r02_j_ab_8x1row.txt): with a residual 330 -> 305 us,
   // without 307 -> 303 us; deeper reductions (128 / 192 / 256 -> 64) are equal, so they keep the tile with less halo.
-  static const bool no8x1r = CM_FP8X || getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob (the experiment's one-row 8-wave tile spills at its 128-register cap)
+  static const bool no8x1r = getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob
   if (!no8x1r && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
   else if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
   else if (!no16 && a.H >= 16 && blocks16 >= 256) v = CMV_16X1, nb = blocks16;
@@ -1526,6 +1390,22 @@ extern "C" int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* ap) {
   const int ns = cm_splits(blocks, (int)mud_cdiv(ap->Cin, 16));
   const int tile_words = ((v == CMV_8X2 || v == CMV_16X1) ? 512 * 64 : v == CMV_MT2 ? 256 * 64 : v == CMV_8X1R ? 512 * 32 : 256 * 32) * (ap->skip_w ? 2 : 1);   // threads x accumulators
   return ns > 1 ? cm_slab_bytes(ns, blocks, tile_words) : 0;
+}
+
+// MUD_PREC_FP8X is built for the two 8-wave two-row tiles (8 x 32 px x 128 ch, 16 x 32 px x 64 ch), i.e. for launches that fill the
+// chip, with the prologues the generators use there (none: G2's gate convolutions; AdaGN + SiLU: the residual blocks).  Not with the
+// fused skip conv: its second accumulator set leaves 128 registers for the rest of the loop, and the plan's operands spill 36-70 of
+// them (scripts/kernel_resources.py) - a caller that wants this plan for a block's Conv_0 runs the 1x1 skip conv as its own launch.
+// The 64 -> 64 layers keep their one-row two-per-CU tile, whose 128-register budget the plan does not fit either.
+static bool cm_fp8x_built(const mud_conv_args& a) {
+  if (a.ks != 3 || a.sub2 || a.skip_w || (a.pro_mode != MUD_PRO_NONE && a.pro_mode != MUD_PRO_AFFINE_SILU)) return false;
+  const int v = cm_variant3(a, nullptr);
+  return v == CMV_8X2 || v == CMV_16X1;
+}
+extern "C" int mud_conv2d_mfma_prec_supported(const mud_conv_args* ap, int prec) {
+  if (!ap || ap->B <= 0 || ap->H <= 0 || ap->W <= 0 || ap->Cin <= 0 || ap->Cout <= 0) return 0;
+  if (prec == MUD_PREC_16X3) return ap->ks == 1 || ap->ks == 3;
+  return prec == MUD_PREC_FP8X && cm_fp8x_built(*ap);
 }
 
 extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
@@ -1565,12 +1445,20 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
                 mud_aligned16(a.skip_w) && mud_aligned16(a.skip_out) && mud_aligned16(a.out),
                 "mud_conv2d_mfma: fused skip conv needs Cin <= 512, Cout %% 4 == 0 and aligned float4 output rows (Cin=%d Cout=%d)", a.Cin, a.Cout);
   }
+  MUD_REQUIRE(a.prec == MUD_PREC_16X3 || a.prec == MUD_PREC_FP8X, "mud_conv2d_mfma: unknown arithmetic plan prec=%d", a.prec);
+  MUD_REQUIRE(a.prec != MUD_PREC_FP8X || (cm_fp8x_built(a) && a.w_exp >= -100 && a.w_exp <= 100),
+              "mud_conv2d_mfma: MUD_PREC_FP8X is not built for this launch (ask mud_conv2d_mfma_prec_supported first; the weights were packed for it and cannot be read by another plan)");
   if (a.B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (a.prec == MUD_PREC_FP8X) {
+    const bool x2 = cm_variant3(a, nullptr) == CMV_8X2;
+    if (a.pro_mode == MUD_PRO_NONE) return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s);
+    return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s);
+  }
   // tile height by problem size: big tiles (more MFMA work per weight byte) once they still fill the 256 CUs
   const int64_t ntiles = mud_cdiv(a.Cout, CM_BN);
-  static const int force_mt = getenv("MUD_CONV_MT") ? atoi(getenv("MUD_CONV_MT")) : 0;   // tuning knob
-  if (force_mt) {
+  static const int force_mt = getenv("MUD_CONV_MT") ? atoi(getenv("MUD_CONV_MT")) : 0;   // tuning knob (plain launches only: the fused skip conv keeps its own tiles)
+  if (force_mt && !a.skip_w) {
     if (a.ks == 3) return (force_mt == 8 && ntiles % 2 == 0) ? cm_launch<3, 2, 4, 2>(a, s) : force_mt == 16 ? cm_launch<3, 2, 8, 1>(a, s) : force_mt == 1 ? cm_launch<3, 1>(a, s) : cm_launch<3, 2>(a, s);
     return cm_launch<1, 1>(a, s);      // (256- and 512-pixel 1x1 tiles were measured 5-8 % slower and are no longer built)
   }

@@ -13,8 +13,10 @@ import os
 import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get('MUDIFF_HIP_LIB', os.path.join(_HERE, 'libmudiff_hip.so'))   # override: kernel experiments
+_SHIPPED = os.path.join(_HERE, 'libmudiff_hip.so')
+_LIB_PATH = os.environ.get('MUDIFF_HIP_LIB', _SHIPPED)   # override: kernel experiments; refused unless MUDIFF_ALLOW_VARIANT=1 (see load())
 _lib = None
+PREC_16X3, PREC_FP8X = 0, 1
 
 ACT_NONE, ACT_SIGMOID, ACT_TANH, ACT_SILU, ACT_LRELU = 0, 1, 2, 3, 4
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SILU, PRO_LRELU = 0, 1, 2, 3
@@ -45,6 +47,7 @@ class ConvArgs(C.Structure):
         ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
         ('splitk_counters', C.c_void_p), ('splitk_ncounters', C.c_int),
         ('skip_w', C.c_void_p), ('skip_bias', C.c_void_p), ('skip_out', C.c_void_p), ('skip_ldo', C.c_int),
+        ('prec', C.c_int), ('w_exp', C.c_int),
     ]
 
 
@@ -66,6 +69,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
     'mud_version': (C.c_int, []),
     'mud_last_error': (C.c_char_p, []),
+    'mud_build_flags': (C.c_char_p, []),
     'mud_posterior_sample': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _P]),
     'mud_q_sample': (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _L, _P]),
     'mud_timestep_embedding': (_I, [_P, _P, _I, _I, _F, _P]),
@@ -80,7 +84,9 @@ _SIGNATURES = {
     'mud_conv2d_direct': (_I, [C.POINTER(ConvArgs), _P]),
     'mud_packed_weight_bytes': (_L, [_I, _I, _I]),
     'mud_pack_weights': (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
+    'mud_pack_weights_prec': (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mud_conv2d_mfma': (_I, [C.POINTER(ConvArgs), _P]),
+    'mud_conv2d_mfma_prec_supported': (_I, [C.POINTER(ConvArgs), _I]),
     'mud_conv2d_mfma_splitk_bytes': (_L, [C.POINTER(ConvArgs)]),
     'mud_upfirdn2d': (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mud_fir_nhwc': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
@@ -103,9 +109,15 @@ def lib_path():
 
 
 def load():
-    """Load libmudiff_hip.so (once).  Fails loudly when it has not been built."""
+    """Load libmudiff_hip.so (once).  Fails loudly when it has not been built.  Only the in-tree shipped build is accepted:
+    another path (MUDIFF_HIP_LIB) or a library that reports experiment flags (mud_build_flags() != "") needs
+    MUDIFF_ALLOW_VARIANT=1 - a stray variant must never serve the product path silently."""
     global _lib
     if _lib is None:
+        allow = os.environ.get('MUDIFF_ALLOW_VARIANT', '0') == '1'
+        if os.path.realpath(_LIB_PATH) != os.path.realpath(_SHIPPED) and not allow:
+            raise MudiffHipError(f'MUDIFF_HIP_LIB={_LIB_PATH} is not the shipped library ({_SHIPPED}); '
+                                 'set MUDIFF_ALLOW_VARIANT=1 to run an experiment build')
         if not os.path.isfile(_LIB_PATH):
             raise MudiffHipError(
                 f'{_LIB_PATH} not found: build it with `make -C mu-diff_amd/csrc` (or __graft_entry__.build()). '
@@ -114,6 +126,9 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        flags = lib.mud_build_flags().decode()
+        if flags and not allow:
+            raise MudiffHipError(f'{_LIB_PATH} is an experiment build ({flags}); set MUDIFF_ALLOW_VARIANT=1 to run it')
         _lib = lib
     return _lib
 

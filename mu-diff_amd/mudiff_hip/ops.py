@@ -8,8 +8,8 @@ import os
 
 import torch
 
-from . import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PRO_AFFINE, PRO_AFFINE_SILU, PRO_LRELU, PRO_NONE, ConvArgs,  # noqa: F401
-               MudiffHipError, check, load, ptr, require_gpu)
+from . import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_SILU, ACT_TANH, PREC_16X3, PREC_FP8X, PRO_AFFINE, PRO_AFFINE_SILU, PRO_LRELU, PRO_NONE,  # noqa: F401
+               ConvArgs, MudiffHipError, check, load, ptr, require_gpu)
 
 
 # MUD_DETERMINISTIC=1: bit-stable outputs run to run.  The only order-dependent arithmetic of the path is the fp64 atomic
@@ -385,22 +385,31 @@ def channel_mean(x: View):
 
 
 # ---------------------------------------------------------------------------------------------------
-def pack_weights(src, s_tap, s_ci, s_co, ks, Cin, Cout, nbatch=1, src_bstride=0, src_offset=0):
-    """-> uint8 tensor [nbatch, packed bytes] in the MFMA kernel's B-operand layout."""
+def pack_weights(src, s_tap, s_ci, s_co, ks, Cin, Cout, nbatch=1, src_bstride=0, src_offset=0, prec=PREC_16X3, w_exp=0):
+    """-> uint8 tensor [nbatch, packed bytes] in the MFMA kernel's B-operand layout (for the arithmetic plan `prec`)."""
     lib = load()
     require_gpu(src)
     nbytes = lib.mud_packed_weight_bytes(ks, Cin, Cout)
     dst = torch.empty(nbatch, nbytes, device=src.device, dtype=torch.uint8)
-    _launch('pack_weights', src.device, lib.mud_pack_weights, C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout, nbatch,
-                               ptr(dst), STREAM)
+    _launch('pack_weights', src.device, lib.mud_pack_weights_prec, C.c_void_p(src.data_ptr() + 4 * src_offset), s_tap, s_ci, s_co, src_bstride, ks, Cin, Cout,
+            nbatch, prec, w_exp, ptr(dst), STREAM)
     return dst
 
 
-def pack_conv_weight(w_oihw):
+def fp8x_weight_exponent(w):
+    """The power-of-two pre-scale of a layer's e4m3 weight image (MUD_PREC_FP8X): the largest e with max|w| * 2^e <= 448 (e4m3's
+    largest finite value), so that the 4 significant bits sit where this layer's weights are.  Host sync: pack time only."""
+    m = float(w.detach().abs().max())
+    if not (m > 0.0) or not math.isfinite(m):
+        return 0
+    return max(-100, min(100, int(math.floor(math.log2(448.0 / m)))))
+
+
+def pack_conv_weight(w_oihw, prec=PREC_16X3, w_exp=0):
     """nn.Conv2d weight [O,I,k,k] -> packed MFMA operand."""
     O, I, k, _ = w_oihw.shape
     w = _f32(w_oihw.detach().contiguous())
-    return pack_weights(w, 1, k * k, I * k * k, k, I, O)
+    return pack_weights(w, 1, k * k, I * k * k, k, I, O, prec=prec, w_exp=w_exp)
 
 
 def pack_matrix_in_out(W_in_out):
@@ -414,12 +423,41 @@ def direct_weight(w_oihw):
     return w_oihw.detach().permute(2, 3, 1, 0).contiguous()
 
 
+# ---- arithmetic plan per 3x3 launch (mud_conv_args.prec).  MUD_PREC_PLAN: 'off' = every launch 16-bit x 3 (bf16 pieces);
+# 'all' = the fp16 + e4m3-cross-term plan wherever the library has it; 'auto' (default) = where it was measured to pay
+# (fp8x_pays): the launches that fill the chip with >= 128 output channels - the 64-output-channel layers at 256x256 are not
+# bound by matrix cycles and keep the exact-er plan.
+PREC_PLAN = os.environ.get('MUD_PREC_PLAN', 'off')
+
+
+def fp8x_pays(B, H, W, cin, cout):
+    return cout >= 128 and cin >= 64
+
+
+def conv_prec_supported(x: View, cout, pro_mode, prec, skip=False, sub2=False):
+    a = ConvArgs()
+    a.x, a.B, a.H, a.W, a.Cin, a.ldx, a.ks, a.stride, a.pad = x.ptr, x.B, x.H, x.W, x.C, x.ld, 3, 1, 1
+    a.out, a.Cout, a.ldo, a.pro_mode, a.sub2 = x.ptr, cout, (cout + 3) & ~3, pro_mode, int(sub2)
+    if skip:
+        a.skip_w = x.ptr
+    return bool(load().mud_conv2d_mfma_prec_supported(C.byref(a), prec))
+
+
+def choose_prec(x: View, cout, pro_mode, *, skip=False, sub2=False, w_bstride=0):
+    """The plan a 3x3 mud_conv2d_mfma launch of this shape runs with."""
+    if PREC_PLAN == 'off' or w_bstride or x.C % 4:
+        return PREC_16X3
+    if PREC_PLAN != 'all' and not fp8x_pays(x.B, x.H, x.W, x.C, cout):
+        return PREC_16X3
+    return PREC_FP8X if conv_prec_supported(x, cout, pro_mode, PREC_FP8X, skip=skip, sub2=sub2) else PREC_16X3
+
+
 def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None, bias2=None, res: View = None,
          out_scale=1.0, act=ACT_NONE, out: View = None, w_bstride=0, arena=None, sub2=False, emul: View = None, gate=None, emul_cout=0,
-         skip=None):
+         skip=None, prec=PREC_16X3, w_exp=0):
     """One fused convolution launch.  pro = (scale [B,Cin], shift [B,Cin], mode).
     skip = (packed 1x1 weights, bias or None, out View): the same launch also writes the 1x1 convolution of the RAW input
-    (the residual block's Conv_2) - see fused_skip_ok()."""
+    (the residual block's Conv_2) - see fused_skip_ok().  prec / w_exp: the arithmetic plan `w` was packed for."""
     lib = load()
     pad = ks // 2 if pad is None else pad
     Ho = (x.H + 2 * pad - ks) // stride + 1
@@ -470,6 +508,7 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
         assert (gv.B, gv.H, gv.W, gv.C) == (x.B, Ho, Wo, Cout) == (ov.B, ov.H, ov.W, ov.C)
         a.egate, a.ld_egate, a.eother, a.ld_eother = gv.ptr, gv.ld, ov.ptr, ov.ld
     a.out, a.Cout, a.ldo = out.ptr, Cout, out.ld
+    a.prec, a.w_exp = prec, w_exp
     if out.stats is not None:
         a.stats, a.stats_ld = out.stats_ptr, out.stats.shape[1]
     skip_flops = 0.0
@@ -486,7 +525,7 @@ def conv(x: View, w, ks, Cout, *, mfma, stride=1, pad=None, pro=None, bias=None,
             keep = (keep, torch.empty(nws, device=x.device, dtype=torch.uint8))
             a.splitk_ws, a.splitk_ws_bytes = ptr(keep[1]), nws
     fn = lib.mud_conv2d_mfma if mfma else lib.mud_conv2d_direct
-    name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}')
+    name = (f'conv_mfma_k{ks}' if mfma else f'conv_direct_k{ks}') + ('_fp8x' if prec == PREC_FP8X else '')
     flops = 2.0 * x.B * Ho * Wo * Cout * x.C * ks * ks + skip_flops     # algorithmic (sub2 issues 4x this)
     nbytes = 4.0 * (x.npix * x.C + out.npix * Cout * ((2 if res is not None else 1) + (1 if skip is not None else 0))) + (w.numel() * w.element_size() if w_bstride == 0 else x.B * w_bstride)
     _launch(name, x.device, fn, C.byref(a), STREAM, flops=flops, nbytes=nbytes)

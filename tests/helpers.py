@@ -44,6 +44,39 @@ def sampler_inputs(cfg, B, seed_x=42):
     return x_init, zs, noises
 
 
+CFG3_MODS = ['FLAIR', 'T2', 'T1', 'T1CE']        # channel order of wide_cfg3.npz's slices_u8 (tests/golden/make_golden.py)
+CFG3_ORDERS = {      # reference dataset/dataset_brats.py:29-34: condition order per target contrast (target last)
+    'T1CE': ['FLAIR', 'T2', 'T1', 'T1CE'],
+    'FLAIR': ['T1CE', 'T1', 'T2', 'FLAIR'],
+    'T2': ['T1CE', 'T1', 'FLAIR', 'T2'],
+    'T1': ['FLAIR', 'T1CE', 'T2', 'T1'],
+}
+
+
+def wide_cfg3_case(cfg, copies=2):
+    """BASELINE config 3 as SURVEY.md section 8(d) item 3 words it (tests/golden/wide_cfg3.npz): 16 distinct BraTS-shaped
+    slices, 4 per target ordering, the reference's own B=4 run of each group with every step's x_new recorded.
+    -> conds [3 x (16*copies,1,H,W)], x_init, zs, noises (the reference's draws, group by group), per-step reference x_new
+    [16,1,H,W], targets [16,H,W] in [-1,1], group names; `copies` replicas of the 16 slices make one batch (2 -> 32)."""
+    gd = load_golden('wide_cfg3.npz')
+    sl = gd['slices_u8'].float() / 255.0 * 2.0 - 1.0                     # [16, 4, H, W]
+    conds = [[], [], []]
+    xs, zs, ns, tgt = [], [[] for _ in range(cfg.num_timesteps)], [[] for _ in range(cfg.num_timesteps)], []
+    for gi, (name, order) in enumerate(CFG3_ORDERS.items()):
+        idx = slice(4 * gi, 4 * gi + 4)
+        for c in range(3):
+            conds[c].append(sl[idx, CFG3_MODS.index(order[c])][:, None])
+        tgt.append(sl[idx, CFG3_MODS.index(order[3])])
+        x_init, z, n = sampler_inputs(cfg, 4, seed_x=314 + gi)
+        xs.append(x_init)
+        for k in range(cfg.num_timesteps):
+            zs[k].append(z[k]); ns[k].append(n[k])
+    rep = lambda parts: torch.cat(parts, 0).repeat(copies, *([1] * (parts[0].dim() - 1))).contiguous()   # noqa: E731
+    refs = [torch.cat([gd[f'{name}.step{k}.xnew'] for name in CFG3_ORDERS], 0) for k in range(cfg.num_timesteps)]
+    return dict(conds=[rep(c) for c in conds], x_init=rep(xs), zs=[rep(z) for z in zs], noises=[rep(n) for n in ns],
+                refs=refs, targets=torch.cat(tgt, 0), groups=list(CFG3_ORDERS))
+
+
 SMALL_CFGS = {
     's32': dict(image_size=32, num_channels_dae=32, ch_mult=[1, 2, 4], attn_resolutions=(16,)),
     's32na': dict(image_size=32, num_channels_dae=16, ch_mult=[1, 2], attn_resolutions=(), num_res_blocks=1),

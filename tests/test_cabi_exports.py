@@ -24,7 +24,8 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/mudiff_hip.h but not exported'
     assert sorted(mudiff_hip.EXPORTED_SYMBOLS) == declared, 'ctypes binding and header disagree'
-    assert lib.mud_version() >= 100
+    assert lib.mud_version() >= 110
+    assert lib.mud_build_flags() == b'', 'the in-tree library must be the clean build (no experiment flags)'
     assert lib.mud_packed_weight_bytes(3, 64, 64) == 1 * 4 * 9 * 4096 + 8192   # tiles * k16 chunks * taps * (hi+lo planes) + DMA slack
     assert lib.mud_packed_weight_bytes(2, 64, 64) == -1
     assert lib.mud_gn_ws_bytes(1, 65536, 256, 32) > 0
@@ -34,8 +35,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     import mudiff_hip
     monkeypatch.setattr(mudiff_hip, '_lib', None)
     monkeypatch.setattr(mudiff_hip, '_LIB_PATH', '/nonexistent/libmudiff_hip.so')
+    monkeypatch.setattr(mudiff_hip, '_SHIPPED', '/nonexistent/libmudiff_hip.so')
     with pytest.raises(mudiff_hip.MudiffHipError, match='no CPU'):
         mudiff_hip.load()
+
+
+def test_only_the_shipped_library_is_loaded_unless_a_variant_is_allowed(monkeypatch, tmp_path):
+    """a stray MUDIFF_HIP_LIB (an experiment build) must not serve the product path silently."""
+    import shutil
+    import mudiff_hip
+    other = tmp_path / 'lib_variant.so'
+    shutil.copy(mudiff_hip._SHIPPED, other)
+    monkeypatch.setattr(mudiff_hip, '_lib', None)
+    monkeypatch.setattr(mudiff_hip, '_LIB_PATH', str(other))
+    monkeypatch.delenv('MUDIFF_ALLOW_VARIANT', raising=False)
+    with pytest.raises(mudiff_hip.MudiffHipError, match='MUDIFF_ALLOW_VARIANT'):
+        mudiff_hip.load()
+    monkeypatch.setenv('MUDIFF_ALLOW_VARIANT', '1')
+    assert mudiff_hip.load().mud_version() >= 110
+    monkeypatch.setattr(mudiff_hip, '_lib', None)      # (do not leave the copy bound for the tests that follow)
 
 
 def test_drop_in_modules_have_reference_state_dict():

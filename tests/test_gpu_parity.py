@@ -34,9 +34,12 @@ def maxdiff(a, b):
 
 # ----------------------------------------------------------------------------------------------
 def test_library_loaded_is_in_tree():
+    import os
     import mudiff_hip
     lib = mudiff_hip.load()
-    assert lib.mud_version() >= 100
+    assert lib.mud_version() >= 110
+    assert lib.mud_build_flags() == b'', 'the GPU suite must run on the clean in-tree build, not on an experiment variant'
+    assert os.path.realpath(mudiff_hip.lib_path()) == os.path.realpath(os.path.join(os.path.dirname(mudiff_hip.__file__), 'libmudiff_hip.so'))
     with open('/proc/self/maps') as f:
         assert 'libmudiff_hip.so' in f.read()
 
@@ -219,6 +222,58 @@ def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
     out = ops.conv(ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ks, Cout, mfma=True, bias=g(b), bias2=g(b2),
                    pro=(g(sc), g(sh), ops.PRO_AFFINE_SILU), res=ops.View.from_nchw(g(res)), out_scale=0.5, act=ops.ACT_TANH).to_nchw()
     assert maxdiff(out, ref) < 3e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,pro,res', [(8, 64, 64, 256, 256, True, True), (4, 128, 128, 128, 128, True, False), (1, 256, 256, 192, 384, False, False),
+                                                     (16, 70, 33, 96, 128, True, True), (16, 128, 128, 192, 64, True, False)])
+def test_conv_fp8x_plan_vs_fp64(B, H, W, Cin, Cout, pro, res):
+    """MUD_PREC_FP8X (fp16 hi.hi + both cross terms on the block-scaled e4m3 MFMA, per-layer weight exponent): against fp64, next to
+    the 16-bit x 3 plan on the same problem.  ~2^-15 per product: rms error within 4x of the 16x3 plan's and <= 4e-5 of the output rms;
+    weights far from unit scale exercise the per-layer exponent."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(B + H + Cin + Cout)
+    for wscale in (1.0, 37.0, 1.0 / 512):
+        x = torch.randn(B, Cin, H, W, generator=gen)
+        w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5 * wscale
+        bias = torch.randn(Cout, generator=gen)
+        sc, sh = torch.rand(B, Cin, generator=gen) + 0.5, torch.randn(B, Cin, generator=gen)
+        r = torch.randn(B, Cout, H, W, generator=gen) if res else None
+        xv = ops.View.from_nchw(g(x))
+        if not ops.conv_prec_supported(xv, Cout, ops.PRO_AFFINE_SILU if pro else ops.PRO_NONE, ops.PREC_FP8X):
+            raise AssertionError('test shape must be one the plan is built for')
+        kw = dict(mfma=True, pro=(g(sc), g(sh), ops.PRO_AFFINE_SILU) if pro else None, bias=g(bias), res=ops.View.from_nchw(g(r)) if res else None)
+        we = ops.fp8x_weight_exponent(w)
+        assert float(w.abs().max()) * 2.0 ** we <= 448.0 < float(w.abs().max()) * 2.0 ** (we + 1)
+        y8 = ops.conv(xv, ops.pack_conv_weight(g(w), prec=ops.PREC_FP8X, w_exp=we), 3, Cout, prec=ops.PREC_FP8X, w_exp=we, **kw).to_nchw().cpu().double()
+        y16 = ops.conv(xv, ops.pack_conv_weight(g(w)), 3, Cout, **kw).to_nchw().cpu().double()
+        h = x.double()
+        if pro:
+            h = torch.nn.functional.silu(h * sc.double()[:, :, None, None] + sh.double()[:, :, None, None])
+        ref = torch.nn.functional.conv2d(h, w.double(), bias.double(), padding=1) + (r.double() if res else 0)
+        rms = lambda e: float(e.pow(2).mean().sqrt())
+        conv_rms = rms(ref - (r.double() if res else 0) - bias.double()[None, :, None, None])
+        e8, e16 = rms(y8 - ref), rms(y16 - ref)
+        print(f'{B}x{H}x{W} {Cin}->{Cout} w x{wscale:g} (2^{we}): rms err fp8x {e8:.2e} 16x3 {e16:.2e}; conv rms {conv_rms:.2f}; max-abs fp8x {float((y8 - ref).abs().max()):.2e}')
+        assert not torch.isnan(y8).any() and e8 <= 4e-5 * max(conv_rms, 1e-3) and e8 <= 6 * e16 + 1e-7
+
+
+def test_c_abi_refuses_a_plan_that_is_not_built_for_the_launch():
+    """Weights packed for MUD_PREC_FP8X cannot be read by another plan, so mud_conv2d_mfma must fail loudly (nothing launched)
+    where the plan does not exist: small grids, the fused skip conv, 1x1 kernels."""
+    import ctypes as C
+    import mudiff_hip
+    ops, *_ = _imports()
+    lib = mudiff_hip.load()
+    x = ops.View(torch.randn(1, 16, 16, 64, device=DEV), 1, 16, 16, 64)
+    assert not ops.conv_prec_supported(x, 64, ops.PRO_AFFINE_SILU, ops.PREC_FP8X)
+    big = ops.View(torch.randn(4, 128, 128, 128, device=DEV), 4, 128, 128, 128)
+    assert ops.conv_prec_supported(big, 128, ops.PRO_AFFINE_SILU, ops.PREC_FP8X) and not ops.conv_prec_supported(big, 128, ops.PRO_AFFINE_SILU, ops.PREC_FP8X, skip=True)
+    w = torch.randn(64, 64, 3, 3, device=DEV)
+    with pytest.raises(mudiff_hip.MudiffHipError, match='MUD_PREC_FP8X is not built'):
+        ops.conv(x, ops.pack_conv_weight(w, prec=ops.PREC_FP8X, w_exp=3), 3, 64, mfma=True, prec=ops.PREC_FP8X, w_exp=3)
+    dst = torch.empty(lib.mud_packed_weight_bytes(1, 64, 64), device=DEV, dtype=torch.uint8)
+    w1 = torch.randn(64, 64, device=DEV)
+    assert lib.mud_pack_weights_prec(C.c_void_p(w1.data_ptr()), 0, 64, 1, 0, 1, 64, 64, 1, 1, 0, C.c_void_p(dst.data_ptr()), None) != 0    # ks == 1 has no fp8x form
 
 
 @pytest.mark.parametrize('mfma,Cin,Cout,H,W', [(True, 32, 96, 20, 37), (True, 64, 64, 64, 64), (False, 1, 64, 31, 17), (False, 8, 24, 16, 16)])
@@ -989,6 +1044,37 @@ def test_config3_brats_shaped_batch32_vs_reference():
         dss.append(O.ssim(tgt, to01(out[i, 0].numpy())) - O.ssim(tgt, to01(ref[i, 0].numpy())))
     print(f'cfg3 B=32: max-abs {err:.2e}, dPSNR {np.mean(dps):+.4f} dB (max {np.abs(dps).max():.4f}), dSSIM {np.mean(dss):+.6f}')
     assert err <= 1e-3 and np.abs(dps).max() <= 0.05 and np.abs(dss).max() <= 0.001
+
+
+def test_config3_wide_16_slices_four_target_orderings_every_step_vs_reference():
+    """BASELINE config 3 as SURVEY.md section 8(d) item 3 specifies it: a BraTS-shaped split over ALL FOUR target orderings
+    (dataset/dataset_brats.py:29-34), batch 32 = 16 distinct slices x 2 through the captured sampler; every reverse step's x_new
+    of every slice against the reference's own B=4 runs (<= 1e-3), PSNR / SSIM of every slice against its synthetic target
+    within +-0.05 dB / +-0.001 of the reference's (tools/metric_calc.py:28-53)."""
+    ops, S, *_ = _imports()
+    from helpers import wide_cfg3_case
+    cfg = O.default_config()
+    g1, g2 = _build(cfg)
+    case = wide_cfg3_case(cfg, copies=2)
+    sampler = S.GraphSampler(S.Posterior_Coefficients(cfg, DEV), g1, g2, cfg, 32, 256, 256, DEV)
+    out, steps = sampler.sample(*[g(c) for c in case['conds']], g(case['x_init']), 4, zs=[g(z) for z in case['zs']],
+                                noises=[g(n) for n in case['noises']], return_steps=True)
+    worst = []
+    for k, st in enumerate(steps):
+        xn = st[2].cpu()
+        per_slice = (xn.view(2, 16, -1) - case['refs'][k].view(1, 16, -1)).abs().amax(dim=2).amax(dim=0)      # both replicas
+        by_group = [float(per_slice[4 * i:4 * i + 4].max()) for i in range(4)]
+        print(f'cfg3 wide step {k}: max-abs per target ordering ' + ' '.join(f'{n} {e:.2e}' for n, e in zip(case['groups'], by_group)))
+        worst.append(max(by_group))
+    to01 = lambda a: (np.asarray(a, np.float64) + 1) / 2
+    ref_final, ours = case['refs'][-1], out.cpu()
+    dps, dss = [], []
+    for i in range(16):
+        tgt = to01(case['targets'][i].numpy())
+        dps.append(O.psnr(tgt, to01(ours[i, 0].numpy())) - O.psnr(tgt, to01(ref_final[i, 0].numpy())))
+        dss.append(O.ssim(tgt, to01(ours[i, 0].numpy())) - O.ssim(tgt, to01(ref_final[i, 0].numpy())))
+    print(f'cfg3 wide: worst per-step max-abs {max(worst):.2e}; dPSNR max |{np.abs(dps).max():.5f}| dB, dSSIM max |{np.abs(dss).max():.6f}| over 16 slices')
+    assert max(worst) <= 1e-3 and np.abs(dps).max() <= 0.05 and np.abs(dss).max() <= 0.001
 
 
 def test_deterministic_switch_gives_bit_stable_outputs():
