@@ -457,9 +457,63 @@ def parity_leg(cfg, dev):
     ours, theirs = x.cpu()[0, 0].numpy(), ref[f'step{cfg.num_timesteps - 1}.xnew'][0, 0].numpy()
     dp = driver.psnr(to01(target), to01(ours)) - driver.psnr(to01(target), to01(theirs))
     ds = driver.ssim(to01(target), to01(ours)) - driver.ssim(to01(target), to01(theirs))
-    return {'fixture': 'tests/golden/full_cfg2.npz (outputs of the reference itself on its demo images, B=1, injected draws)',
-            'max_abs_per_step': [float(f'{e:.3e}') for e in per_step], 'tolerance': 1e-3, 'dpsnr_db': round(dp, 5), 'dssim': round(ds, 6),
-            'ok': bool(max(per_step) <= 1e-3 and abs(dp) <= 0.05 and abs(ds) <= 0.001)}
+    out = {'fixture': 'tests/golden/full_cfg2.npz (outputs of the reference itself on its demo images, B=1, injected draws)',
+           'max_abs_per_step': [float(f'{e:.3e}') for e in per_step], 'tolerance': 1e-3, 'dpsnr_db': round(dp, 5), 'dssim': round(ds, 6),
+           'ok': bool(max(per_step) <= 1e-3 and abs(dp) <= 0.05 and abs(ds) <= 0.001)}
+    del sampler
+    wide = parity_wide_cfg3(cfg, dev, g1, g2)
+    out['config3_wide'] = wide
+    out['ok'] = bool(out['ok'] and wide['ok'])
+    return out
+
+
+def parity_wide_cfg3(cfg, dev, g1, g2):
+    """BASELINE config 3 (tests/golden/wide_cfg3.npz): 16 distinct BraTS-shaped slices, 4 per target ordering
+    (dataset/dataset_brats.py:29-34), the reference's own B=4 runs with every step's x_new - here as ONE batch of 32 (each slice
+    twice) through the captured sampler, i.e. exactly the headline workload.  Worst per-step max-abs over the 16 slices, and the
+    worst PSNR / SSIM difference to the reference per slice (tools/metric_calc.py:28-53 definitions, same code on both sides)."""
+    import numpy as np
+    from mudiff_hip import driver, sampling as S
+    orders = {'T1CE': ['FLAIR', 'T2', 'T1', 'T1CE'], 'FLAIR': ['T1CE', 'T1', 'T2', 'FLAIR'], 'T2': ['T1CE', 'T1', 'FLAIR', 'T2'], 'T1': ['FLAIR', 'T1CE', 'T2', 'T1']}
+    mods = ['FLAIR', 'T2', 'T1', 'T1CE']
+    with np.load(os.path.join(REPO, 'tests', 'golden', 'wide_cfg3.npz'), allow_pickle=False) as z:
+        gd = {k: torch.from_numpy(z[k]) for k in z.files}
+    sl = gd['slices_u8'].float() / 255.0 * 2.0 - 1.0
+    H, T = cfg.image_size, cfg.num_timesteps
+    conds, xs, zs, ns, tg = [[], [], []], [], [[] for _ in range(T)], [[] for _ in range(T)], []
+    for gi, order in enumerate(orders.values()):
+        idx = slice(4 * gi, 4 * gi + 4)
+        for c in range(3):
+            conds[c].append(sl[idx, mods.index(order[c])][:, None])
+        tg.append(sl[idx, mods.index(order[3])])
+        gen = torch.Generator().manual_seed(314 + gi)            # the draws of tests/golden/make_golden.py::golden_cfg3_wide (tests/helpers.py::sampler_inputs)
+        xs.append(torch.randn(4, 1, H, H, generator=gen))
+        st = torch.get_rng_state()
+        torch.manual_seed(315 + gi)
+        for k in range(T):
+            zs[k].append(torch.randn(4, cfg.nz))
+            ns[k].append(torch.randn(4, 1, H, H))
+        torch.set_rng_state(st)
+    rep = lambda parts: torch.cat(parts, 0).repeat(2, *([1] * (parts[0].dim() - 1))).contiguous().to(dev)      # noqa: E731
+    sampler = S.GraphSampler(S.Posterior_Coefficients(cfg, dev), g1, g2, cfg, 32, H, H, dev)
+    x, steps = sampler.sample(rep(conds[0]), rep(conds[1]), rep(conds[2]), rep(xs), T, zs=[rep(z) for z in zs], noises=[rep(n) for n in ns], return_steps=True)
+    per_step = []
+    for k, stp in enumerate(steps):
+        ref = torch.cat([gd[f'{name}.step{k}.xnew'] for name in orders], 0)
+        per_step.append(float((stp[2].cpu().view(2, 16, -1) - ref.view(1, 16, -1)).abs().max()))
+    ref_final = torch.cat([gd[f'{name}.step{T - 1}.xnew'] for name in orders], 0)
+    targets = torch.cat(tg, 0)
+    to01 = lambda t: (np.asarray(t, np.float64) + 1) / 2          # noqa: E731
+    dps, dss = [], []
+    ours = x.cpu()
+    for i in range(16):
+        t = to01(targets[i].numpy())
+        dps.append(driver.psnr(t, to01(ours[i, 0].numpy())) - driver.psnr(t, to01(ref_final[i, 0].numpy())))
+        dss.append(driver.ssim(t, to01(ours[i, 0].numpy())) - driver.ssim(t, to01(ref_final[i, 0].numpy())))
+    return {'fixture': 'tests/golden/wide_cfg3.npz (the reference\'s B=4 runs of 16 synthetic slices over the 4 target orderings; here one batch of 32)',
+            'max_abs_per_step': [float(f'{e:.3e}') for e in per_step], 'dpsnr_db_max_abs': round(float(np.abs(dps).max()), 5),
+            'dssim_max_abs': round(float(np.abs(dss).max()), 6),
+            'ok': bool(max(per_step) <= 1e-3 and np.abs(dps).max() <= 0.05 and np.abs(dss).max() <= 0.001)}
 
 
 def timed_batches(sampler_fn, n_iter):
@@ -610,7 +664,7 @@ def worker(a):
         'metric': METRIC, 'value': round(value, 3), 'unit': 'slices/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * dt / K, 3), 'higher_is_better': True,
         'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (convs/attention: bf16 hi+lo split MFMA x3, fp32 accumulate)',
+        'dtype': 'f32 (convs/attention: fp16 hi+lo split MFMA x3; 3x3 convs that fill the chip: fp16 hi.hi + e4m3 cross terms; fp32 accumulate)',
         'data': 'synthetic', 'ranks_seen': ranks_seen,
         **({'per_rank': per_rank, 'param_broadcast': bcast} if world > 1 else {}),
         'config': {'workload': workload, 'slices_per_gpu_per_step': n_local, 'batch': B, 'hipgraph': not a.no_graph,
@@ -625,17 +679,24 @@ def worker(a):
         torch.cuda.synchronize()
         prof = ops.PROFILE.summary()
         ops.PROFILE.disable()
-        k = prof.get('conv_mfma_k3')
-        if k:
+        # the dominant kernel = k_conv_mfma<3> under both of its arithmetic plans (ops.conv names the launches conv_mfma_k3 / conv_mfma_k3_fp8x)
+        parts = {n: v for n, v in prof.items() if n.startswith('conv_mfma_k3')}
+        if parts:
+            k = {f: sum(v[f] for v in parts.values()) for f in ('n', 'ms', 'flops', 'bytes')}
+            x8 = parts.get('conv_mfma_k3_fp8x', dict(n=0, ms=0.0, flops=0.0))
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
+            # 16-bit-MFMA cycles issued per algorithmic FLOP: 3 under the fp16 x 3 plan, 7/3 under fp16 + e4m3 cross terms (224 / 96 cycles
+            # per 3-tap group; the e4m3 MFMA counted at its cycles, i.e. in 16-bit equivalents)
+            issued = (3.0 * (k['flops'] - x8['flops']) + 7.0 / 3.0 * x8['flops']) / (k['ms'] * 1e-3) / 1e12
             traffic, tsrc = traffic_from_profiles()
-            line['roofline'] = {'kernel': 'k_conv_mfma<3> (3x3 implicit GEMM, split-bf16 MFMA)', 'bound': 'mfma',
+            line['roofline'] = {'kernel': 'k_conv_mfma<3> (3x3 implicit GEMM; split-fp16 MFMA x3, or fp16 hi.hi + e4m3 cross terms)', 'bound': 'mfma',
                                 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
                                 'traffic': traffic, 'traffic_source': tsrc,
                                 'launches': k['n'], 'avg_launch_us': round(1e3 * k['ms'] / k['n'], 2),
                                 'algorithmic_gflop_per_launch': round(k['flops'] / k['n'] / 1e9, 3),
                                 'algorithmic_bytes_per_launch': int(k['bytes'] / k['n']),
-                                'issued_bf16_tflops': round(3 * ach, 2), 'issued_frac': round(3 * ach / PEAK_BF16_TFLOPS, 4),
+                                'issued_16bit_equiv_tflops': round(issued, 2), 'issued_frac': round(issued / PEAK_BF16_TFLOPS, 4),
+                                'fp8x_plan': {'launches': x8['n'], 'share_of_flops': round(x8['flops'] / k['flops'], 3), 'ms': round(x8['ms'], 3)},
                                 'vs_fp32_peak_157.3': round(ach / PEAK_FP32_TFLOPS, 3),
                                 'share_of_gpu_time': round(k['ms'] / sum(v['ms'] for v in prof.values()), 3)}
             line['kernel_time_ms_per_batch'] = {n: round(v['ms'], 3) for n, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
@@ -644,7 +705,7 @@ def worker(a):
     per_gpu = value / world
     line['end_to_end'] = {'flop_per_slice_issued': round(flop_per_slice / 1e9, 1), 'flop_per_slice_reference_graph': round(FLOP_PER_SLICE / 1e9, 1),
                           'fp32_flop_frac': round(per_gpu * flop_per_slice / 1e12 / PEAK_FP32_TFLOPS, 4),
-                          'bf16x3_issued_frac': round(3 * per_gpu * flop_per_slice / 1e12 / PEAK_BF16_TFLOPS, 4),
+                          'x3_issued_frac': round(3 * per_gpu * flop_per_slice / 1e12 / PEAK_BF16_TFLOPS, 4),
                           'fused_hbm_frac': round(per_gpu * FUSED_BYTES_PER_SLICE / 1e9 / PEAK_HBM_GBS, 4)}
 
     extras = rank == 0 and world == 1 and not a.no_extras and not a.no_graph
@@ -673,7 +734,7 @@ def worker(a):
             line[key] = {'slices_per_s': round(iters * nb_ / timed_batches(fn, iters), 2), 'timed_batches': iters,
                          'note': f'same path, {nb_} slice(s) per step' + (' (BASELINE config 2 read literally)' if nb_ == 1 else '')}
             del sb, cs, xb
-        log('parity leg: config 2 fixture through the captured sampler ...')
+        log('parity leg: config 2 and wide config 3 fixtures through the captured sampler ...')
         line['parity'] = parity_leg(cfg, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log('timing the CPU oracle (2 warm-up + 3 timed slices, all cores' + (', then B=8 and 1 thread' if a.cpu_baseline_full else '') + ') ...')

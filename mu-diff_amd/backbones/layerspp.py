@@ -311,8 +311,6 @@ class ResnetBlockBigGANpp_Adagn(nn.Module, _Prepared):
         else:
             x_skip = x
             fused = 'c2' in p and p['c0'].mfma and p['c2'].mfma and ops.fused_skip_ok(x, self.out_ch, PRO_AFFINE_SILU)
-            if fused and p['c0'].plan(x, (sc0, sh0, PRO_AFFINE_SILU)) == ops.PREC_FP8X:
-                fused = False      # the cheaper-cross-term plan has no fused-skip form: Conv_0 takes it and Conv_2 is its own (HBM-bound) launch
             if fused:       # Conv_0 and the 1x1 skip Conv_2 read the same x: one launch stages it once and writes both
                 x_skip = View.empty(x.B, x.H, x.W, self.out_ch, x.device)
                 h = p['c0'](x, pro=(sc0, sh0, PRO_AFFINE_SILU), bias2=tbias, arena=arena, skip=(p['c2'].w, p['c2'].bias, x_skip))

@@ -1,8 +1,8 @@
 // Fused single-head self-attention for AttnBlockpp (reference backbones/layerspp.py:118-122):
 //     out[b,i,:] = sum_j softmax_j(q_i . k_j * scale) v_j        N = H*W positions, head dim C <= 256
 // Flash-style: the N x N score matrix never exists in memory (the unfused path wrote, re-read twice and read
-// again 4*N*N bytes per sample).  Same split-bf16 arithmetic as the convolutions: every fp32 operand is
-// hi + lo bf16 and every product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+// again 4*N*N bytes per sample).  Same split arithmetic as the convolutions (mud_common.h): every fp32 operand is
+// hi + lo fp16 and every product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate).
 //
 // One workgroup = 4 waves = 128 queries (32 per wave), one wave per SIMD (the kernel owns the register file:
 // Q as 2*C/16 B-fragments and the C x 32 output accumulator stay in registers for the whole key loop).
@@ -22,7 +22,7 @@ struct AtGeo {
   static constexpr int C = 16 * C16;
   static constexpr int CT = (C16 + 1) / 2;            // 32-channel output tiles
   static constexpr int CP = CT * 32;                  // channels padded to a multiple of 32
-  static constexpr int KROW = C * 4 + 16;             // LDS bytes per key row: [hi C x bf16 | lo C x bf16 | pad]
+  static constexpr int KROW = C * 4 + 16;             // LDS bytes per key row: [hi C x fp16 | lo C x fp16 | pad]
   static constexpr int VROW = 144;                    // LDS bytes per channel row: [hi 32 keys | lo 32 keys | pad]
   static constexpr int KT = 32 * KROW, VT = CP * VROW;
   static constexpr int BUF = KT + VT;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
   const int ntiles = min((N + 31) / 32, kt0 + tiles_per_split);
 
   // ---- Q^T B-fragments, split once: lane (query r, k half hh) holds channels 16s + 8hh .. +7 of its query
-  bf16x8 qh[C16], ql[C16];
+  mud_h16x8 qh[C16], ql[C16];
 #pragma unroll
   for (int s = 0; s < C16; ++s) {
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
+      mud_h16 h0, h1, l0, l1;
+      mud_split1(v0[e], h0, l0);
+      mud_split1(v1[e], h1, l1);
       qh[s][e] = h0; qh[s][4 + e] = h1;
-      ql[s][e] = (__bf16)(v0[e] - (float)h0); ql[s][4 + e] = (__bf16)(v1[e] - (float)h1);
+      ql[s][e] = l0; ql[s][4 + e] = l1;
     }
   }
 
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
     for (int i = 0; i < G::KN; ++i) {
       const int item = tid + 256 * i, j = item / (C / 4), c4 = item % (C / 4);
       if (item < G::KITEMS) {
-        const bf16x4 hi = __builtin_convertvector(kraw[i], bf16x4);
-        const bf16x4 lo = __builtin_convertvector(kraw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
-        *(bf16x4*)(buf + j * G::KROW + c4 * 8) = hi;
-        *(bf16x4*)(buf + j * G::KROW + C * 2 + c4 * 8) = lo;
+        mud_h16x4 hi, lo;
+        mud_split4(kraw[i], hi, lo);
+        *(mud_h16x4*)(buf + j * G::KROW + c4 * 8) = hi;
+        *(mud_h16x4*)(buf + j * G::KROW + C * 2 + c4 * 8) = lo;
       }
     }
   };
@@ -115,16 +117,17 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
         // keys 4g..4g+3 of the tile -> k-step s, lane half h, element block: the order in which the S^T accumulator
         // registers enumerate keys (element e of half h of step s is key 16s + 8(e>>2) + 4h + (e&3))
         const int jj = (4 * g) & 15, s = (4 * g) >> 4, h = (jj >> 2) & 1, blk = (jj >> 3) & 1;
-        bf16x4 hi, lo;
+        mud_h16x4 hi, lo;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const __bf16 t = (__bf16)vraw[i][u];
-          hi[u] = t;
-          lo[u] = (__bf16)(vraw[i][u] - (float)t);
+          mud_h16 th, tl;
+          mud_split1(vraw[i][u], th, tl);
+          hi[u] = th;
+          lo[u] = tl;
         }
         char* p = buf + G::KT + c * G::VROW + s * 32 + h * 16 + blk * 8;
-        *(bf16x4*)p = hi;
-        *(bf16x4*)(p + 64) = lo;
+        *(mud_h16x4*)p = hi;
+        *(mud_h16x4*)(p + 64) = lo;
       }
     }
   };
@@ -155,11 +158,11 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
 #pragma unroll
     for (int s = 0; s < C16; ++s) {
       const char* kp = cur + r * G::KROW + (16 * s + 8 * hh) * 2;
-      const bf16x8 kh = *(const bf16x8*)kp;
-      const bf16x8 kl = *(const bf16x8*)(kp + C * 2);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
+      const mud_h16x8 kh = *(const mud_h16x8*)kp;
+      const mud_h16x8 kl = *(const mud_h16x8*)(kp + C * 2);
+      st = mud_mfma16(kl, qh[s], st);
+      st = mud_mfma16(kh, ql[s], st);
+      st = mud_mfma16(kh, qh[s], st);
       if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads from piling up in registers
     }
     if (more) {
@@ -194,15 +197,15 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
     }
 
     // ---- P^T B-fragments straight from the accumulator registers: step s2 = registers 8*s2 .. 8*s2+7
-    bf16x8 ph[2], pl[2];
+    mud_h16x8 ph[2], pl[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float p = st[8 * s2 + e];
-        const __bf16 t = (__bf16)p;
+        const mud_h16 t = (mud_h16)p;      // p in [0, 1]: no saturation needed; tiny probabilities are fp16 subnormals, which the MFMA keeps
         ph[s2][e] = t;
-        pl[s2][e] = (__bf16)(p - (float)t);
+        pl[s2][e] = (mud_h16)(p - (float)t);
       }
 
     // ---- O^T += V^T . P^T
@@ -211,11 +214,11 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float* __restrict__ 
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const char* vp = cur + G::KT + (ct * 32 + r) * G::VROW + s2 * 32 + hh * 16;
-        const bf16x8 vh = *(const bf16x8*)vp;
-        const bf16x8 vl = *(const bf16x8*)(vp + 64);
-        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[ct], 0, 0, 0);
-        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[ct], 0, 0, 0);
-        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[ct], 0, 0, 0);
+        const mud_h16x8 vh = *(const mud_h16x8*)vp;
+        const mud_h16x8 vl = *(const mud_h16x8*)(vp + 64);
+        o[ct] = mud_mfma16(vl, ph[s2], o[ct]);
+        o[ct] = mud_mfma16(vh, pl[s2], o[ct]);
+        o[ct] = mud_mfma16(vh, ph[s2], o[ct]);
       }
       if ((ct & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -274,7 +277,7 @@ struct At2Geo {
   static constexpr int C = 16 * C16;
   static constexpr int H16 = C16 / 2;                 // k16 steps of a wave's channel half
   static constexpr int CTH = C16 / 4;                 // 32-channel output tiles of a wave's half
-  static constexpr int KROW = C * 4 + 16;             // LDS bytes per key row: [hi C x bf16 | lo C x bf16 | pad]
+  static constexpr int KROW = C * 4 + 16;             // LDS bytes per key row: [hi C x fp16 | lo C x fp16 | pad]
   static constexpr int VROW = 144;                    // LDS bytes per channel row: [hi 32 keys | lo 32 keys | pad]
   static constexpr int KT = 32 * KROW, VT = C * VROW;
   static constexpr int V_OFF = 2 * KT, X_OFF = V_OFF + VT;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
   const int ntiles = min((N + 31) / 32, kt0 + tiles_per_split);
 
   // ---- Q^T B-fragments of this wave's channel half
-  bf16x8 qh[H16], ql[H16];
+  mud_h16x8 qh[H16], ql[H16];
 #pragma unroll
   for (int s = 0; s < H16; ++s) {
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
@@ -310,9 +313,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
+      mud_h16 h0, h1, l0, l1;
+      mud_split1(v0[e], h0, l0);
+      mud_split1(v1[e], h1, l1);
       qh[s][e] = h0; qh[s][4 + e] = h1;
-      ql[s][e] = (__bf16)(v0[e] - (float)h0); ql[s][4 + e] = (__bf16)(v1[e] - (float)h1);
+      ql[s][e] = l0; ql[s][4 + e] = l1;
     }
   }
 
@@ -339,10 +344,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
 #pragma unroll
     for (int i = 0; i < G::KN; ++i) {
       const int item = tid + 512 * i, j = item / (C / 4), c4 = item % (C / 4);
-      const bf16x4 hi = __builtin_convertvector(kraw[i], bf16x4);
-      const bf16x4 lo = __builtin_convertvector(kraw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
-      *(bf16x4*)(buf + j * G::KROW + c4 * 8) = hi;
-      *(bf16x4*)(buf + j * G::KROW + C * 2 + c4 * 8) = lo;
+      mud_h16x4 hi, lo;
+      mud_split4(kraw[i], hi, lo);
+      *(mud_h16x4*)(buf + j * G::KROW + c4 * 8) = hi;
+      *(mud_h16x4*)(buf + j * G::KROW + C * 2 + c4 * 8) = lo;
     }
   };
   auto stash_v = [&]() {
@@ -352,16 +357,17 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
       // keys 4g..4g+3 of the tile -> k-step s, lane half h, element block: the order in which the S^T accumulator
       // registers enumerate keys (element e of half h of step s is key 16s + 8(e>>2) + 4h + (e&3))
       const int jj = (4 * g) & 15, s = (4 * g) >> 4, h = (jj >> 2) & 1, blk = (jj >> 3) & 1;
-      bf16x4 hi, lo;
+      mud_h16x4 hi, lo;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const __bf16 t = (__bf16)vraw[i][u];
-        hi[u] = t;
-        lo[u] = (__bf16)(vraw[i][u] - (float)t);
+        mud_h16 th, tl;
+        mud_split1(vraw[i][u], th, tl);
+        hi[u] = th;
+        lo[u] = tl;
       }
       char* p = smem + G::V_OFF + c * G::VROW + s * 32 + h * 16 + blk * 8;
-      *(bf16x4*)p = hi;
-      *(bf16x4*)(p + 64) = lo;
+      *(mud_h16x4*)p = hi;
+      *(mud_h16x4*)(p + 64) = lo;
     }
   };
 
@@ -393,11 +399,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
 #pragma unroll
     for (int s = 0; s < H16; ++s) {
       const char* kp = cur + r * G::KROW + (16 * (half * H16 + s) + 8 * hh) * 2;
-      const bf16x8 kh = *(const bf16x8*)kp;
-      const bf16x8 kl = *(const bf16x8*)(kp + C * 2);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], st, 0, 0, 0);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
+      const mud_h16x8 kh = *(const mud_h16x8*)kp;
+      const mud_h16x8 kl = *(const mud_h16x8*)(kp + C * 2);
+      st = mud_mfma16(kl, qh[s], st);
+      st = mud_mfma16(kh, ql[s], st);
+      st = mud_mfma16(kh, qh[s], st);
     }
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) xmine[q4 * 64] = f32x4{st[4 * q4], st[4 * q4 + 1], st[4 * q4 + 2], st[4 * q4 + 3]};
@@ -440,15 +446,15 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[ct][i] *= alpha;
     }
-    bf16x8 ph[2], pl[2];
+    mud_h16x8 ph[2], pl[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float p = st[8 * s2 + e];
-        const __bf16 t = (__bf16)p;
+        const mud_h16 t = (mud_h16)p;      // p in [0, 1]: no saturation needed; tiny probabilities are fp16 subnormals, which the MFMA keeps
         ph[s2][e] = t;
-        pl[s2][e] = (__bf16)(p - (float)t);
+        pl[s2][e] = (mud_h16)(p - (float)t);
       }
 
     // ---- O^T[my channel half] += V^T . P^T
@@ -457,11 +463,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_pair(const float* __restri
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const char* vp = smem + G::V_OFF + ((half * CTH + ct) * 32 + r) * G::VROW + s2 * 32 + hh * 16;
-        const bf16x8 vh = *(const bf16x8*)vp;
-        const bf16x8 vl = *(const bf16x8*)(vp + 64);
-        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[ct], 0, 0, 0);
-        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[ct], 0, 0, 0);
-        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[ct], 0, 0, 0);
+        const mud_h16x8 vh = *(const mud_h16x8*)vp;
+        const mud_h16x8 vl = *(const mud_h16x8*)(vp + 64);
+        o[ct] = mud_mfma16(vl, ph[s2], o[ct]);
+        o[ct] = mud_mfma16(vh, pl[s2], o[ct]);
+        o[ct] = mud_mfma16(vh, ph[s2], o[ct]);
       }
     }
     __syncthreads();                    // every wave is done with the V tile (and with its partner's exchange slot)

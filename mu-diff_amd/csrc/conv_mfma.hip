@@ -2,17 +2,18 @@
 //
 //   out[p, co] = sum_{tap, ci} f(x[p + off(tap), ci]) * w[tap, ci, co]         (ks = 3, pad 1 | ks = 1)
 //
-// gfx950 has no TF32; exact-fp32 MFMA runs at the VALU rate (157 TF), 1/16 of the bf16 rate.  The
+// gfx950 has no TF32; exact-fp32 MFMA runs at the VALU rate (157 TF), 1/16 of the 16-bit rate.  The
 // path needs fp32-class results (<= 1e-3 after ~50 layers), so each fp32 operand is split into two
-// bf16 terms (hi = rne(v), lo = rne(v - hi)) and every product is issued as
-//      lo*hi + hi*lo + hi*hi          (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)
-// i.e. ~2^-17 relative error per product at 16/3 = 5.3x the fp32-MFMA rate.
+// fp16 terms (hi = rne(v), lo = rne(v - hi); mud_common.h) and every product is issued as
+//      lo*hi + hi*lo + hi*hi          (3 x v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// i.e. ~2^-22 relative error per product at 16/3 = 5.3x the fp32-MFMA rate; a second plan (MUD_PREC_FP8X, below) issues the
+// two cross terms on the block-scaled e4m3 MFMA instead: 2^-15 per product at 0.78x the matrix cycles.
 //
 // Structure (one 256-thread workgroup = 4 waves, template <KS, MT>):
 //   * output tile: (4*MT) rows x 32 columns of pixels (ks=3) or 128*MT flat positions (ks=1) x 64
 //     channels; wave w owns MT rows -> MT x 2 MFMA tiles of 32x32 (MT = 4: 128 accumulator regs).
 //   * A operand (activations): the (rows+2) x 34 halo tile of one 16-channel K chunk lives in LDS as
-//     80-byte pixel records [hi 16 x bf16 | lo 16 x bf16 | 16 B pad], so every MFMA A fragment is one
+//     80-byte pixel records [hi 16 x fp16 | lo 16 x fp16 | 16 B pad], so every MFMA A fragment is one
 //     ds_read_b128 at base + (compile-time tap/row offset): the 80-B stride spreads the 16 lanes of a
 //     b128 read group over 16 distinct 16-B bank slots (conflict-free) with NO per-tap address maths.  It is transformed ONCE on the way in (GroupNorm/AdaGN affine, SiLU, hi/lo split)
 //     and reused by 9 taps x 64 output channels.  Double-buffered: the raw fp32 values of chunk k+1
@@ -36,30 +37,16 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// ---- arithmetic plans of a launch (mud_conv_args.prec)
-//   MUD_PREC_16X3  every product as lo*hi + hi*lo + hi*hi on the 16-bit MFMA (3 x v_mfma_f32_32x32x16): the two 16-bit pieces
-//                  of an fp32 operand are h16 = bf16 (8-bit pieces, fp32's exponent range; ~2^-17 per product).
-//   MUD_PREC_FP8X  hi*hi on the fp16 MFMA (11-bit pieces) + the two cross terms of a 3-tap group as TWO block-scaled e4m3 MFMAs
+// ---- arithmetic plans of a launch (mud_conv_args.prec); 16-bit pieces: mud_common.h (fp16 hi + lo)
+//   MUD_PREC_16X3  every product as lo*hi + hi*lo + hi*hi on the fp16 MFMA (3 x v_mfma_f32_32x32x16_f16): ~2^-22 per product.
+//   MUD_PREC_FP8X  hi*hi on the fp16 MFMA + the two cross terms of a 3-tap group as TWO block-scaled e4m3 MFMAs
 //                  (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = (3 taps + a zero tap) x 16 channels, 2x the 16-bit rate):
 //                  288 -> 224 matrix cycles per 3-tap group and accumulator.  The cross terms carry 2^-11 of a product, so 4
 //                  significant bits per operand keep the total at ~2^-15.  3x3 kernel only; same LDS images and weight steps:
 //                  pixel record [f16 hi 32 B][e4m3 a*2^SA 16 B][e4m3 a_lo*2^SAL 16 B][16 B zero = the zero tap],
 //                  weight step  [f16 hi 2 KiB][e4m3 w*2^w_exp 1 KiB][e4m3 w_lo*2^(w_exp+11) 1 KiB]  (w_exp: per layer, chosen at pack time).
-typedef __bf16 h16;                                   // the 16-bit piece type of MUD_PREC_16X3
-typedef h16 h16x4 __attribute__((ext_vector_type(4)));
-typedef h16 h16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 cm_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x16 cm_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-// v = hi + lo (+ ~2^-2p |v|), both pieces in the 16-bit type of V4; fp16 pieces saturate at +-65504 instead of overflowing to inf
-template <typename V4>
-__device__ __forceinline__ void cm_split4(f32x4 v, V4& hi, V4& lo) {
-  if constexpr (std::is_same<V4, f16x4>::value) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
-  }
-  hi = __builtin_convertvector(v, V4);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), V4);
-}
+typedef mud_h16x4 h16x4;
+typedef mud_h16x8 h16x8;
 #define CM_X_SA 2                // constant power-of-two pre-scales of the e4m3 activation images (undone by the MFMA's E8M0 scale operands):
 #define CM_X_SAL 13              // a*2^2 covers |a| in [5e-4, 112]; a_lo <= 2^-11 |a| -> a_lo*2^13 <= 448 as well.  Out-of-range values only lose their cross term
 __device__ __forceinline__ int cm_e4m3x4(f32x4 v, float scale) {    // 4 floats * scale -> 4 packed OCP e4m3 bytes (hardware converter)
@@ -71,7 +58,7 @@ __device__ __forceinline__ int cm_e4m3x4(f32x4 v, float scale) {    // 4 floats 
   return __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true);
 }
 #define CM_BN 64
-#define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] bf16 plane
+#define CM_BPLANE (CM_BN * 32)   // bytes of one [64 co][16 ci] 16-bit plane
 #define CM_BSTEP (2 * CM_BPLANE) // hi plane + lo plane of one (k16 chunk, tap)
 #define CM_PIX 80                // LDS bytes per pixel record of the A tile
 #define CM_GN_MAXC 1024         // most channels the folded GroupNorm finalisation takes (scale | shift arrays in LDS: up to 8 KiB)
@@ -152,7 +139,7 @@ __device__ __forceinline__ void cm_gn_to_lds(const mud_conv_args& a, int b, int 
 }
 
 __device__ __forceinline__ float cm_fast_silu(float v) {
-  // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): the result is rounded to bf16 hi+lo (2^-17) anyway
+  // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp): the result is rounded to fp16 hi+lo (2^-22) anyway
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
@@ -172,8 +159,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   using G = CmGeo<KS, MT, WM, WN, DUAL>;
   constexpr bool X8 = PREC == MUD_PREC_FP8X;           // fp16 hi.hi + e4m3 cross terms (3x3 only)
   static_assert(!X8 || KS == 3, "the fp8 cross-term plan is built for the 3x3 kernel");
-  using HV4 = typename std::conditional<X8, f16x4, h16x4>::type;      // 16-bit pieces of the conv's own operands
-  using HV8 = typename std::conditional<X8, f16x8, h16x8>::type;
+  using HV4 = h16x4;
+  using HV8 = h16x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles
@@ -291,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
       HV4 hi, lo;
-      cm_split4(v, hi, lo);
+      mud_split4(v, hi, lo);
       *(HV4*)(buf + loff[j]) = hi;
       if constexpr (X8) {                       // (loff holds record + 8 q)
         const f32x4 lof = v - __builtin_convertvector(hi, f32x4);                            // exact in fp32 (|v| <= 65504 here or saturated: see cm_split4)
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         if (loff2[j] >= 0) {
           const f32x4 rv = raw[j] * (cvalid ? 1.0f : 0.0f);
           h16x4 rhi, rlo;
-          cm_split4(rv, rhi, rlo);
+          mud_split4(rv, rhi, rlo);
           char* a2 = smem + G::A2_OFF;
           *(h16x4*)(a2 + loff2[j]) = rhi;
           *(h16x4*)(a2 + (loff2[j] ^ 32)) = rlo;          // unit u -> u ^ 2: the lo half sits two 16-B units away under the same swizzle
@@ -351,8 +338,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   // (operand map checked by scripts/mfma_f8_layout.hip).  Every address is a per-lane base with the lane-half dependence folded in
   // + a compile-time offset, like the rest of the loop's LDS reads.
   const int xa_lane0 = lane_a - hh * 16 + hh * (2 * CM_PIX);                        // e4m3 operand, first 16 bytes: the record of tap 0 (hh = 0) / tap 2 (hh = 1)
-  const int xa_lane1_t0 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 48);  // second 16 bytes, term 0 (a_lo image at +48): tap 1 / the zero padding of tap 2's record
-  const int xa_lane1_t1 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 32);  // term 1 (a image at +32)
+  const int xa_lane1_t0 = lane_a - hh * 16 + (hh ? 2 * CM_PIX + 64 : CM_PIX + 48);  // second 16 bytes, term 0 (a_lo image at +48; term 1's a image sits 16 bytes below): tap 1 / the zero padding of tap 2's record
   const int xb_lane = r * 16 + hh * (2 * CM_BSTEP);
   // E8M0 scale operands (2^(byte - 127), the same in every byte) take the constant pre-scales of the e4m3 images back out
   const int s_a = (127 - CM_X_SA) * 0x01010101, s_al = (127 - CM_X_SAL) * 0x01010101;
@@ -449,9 +435,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
           const h16x8 al = *(const h16x8*)((const char*)((uintptr_t)a2 ^ 32));
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            acc2[m][n] = cm_mfma16(al, bh[n], acc2[m][n]);
-            acc2[m][n] = cm_mfma16(ah, bl[n], acc2[m][n]);
-            acc2[m][n] = cm_mfma16(ah, bh[n], acc2[m][n]);
+            acc2[m][n] = mud_mfma16(al, bh[n], acc2[m][n]);
+            acc2[m][n] = mud_mfma16(ah, bl[n], acc2[m][n]);
+            acc2[m][n] = mud_mfma16(ah, bh[n], acc2[m][n]);
           }
         }
       }
@@ -476,18 +462,18 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
             const HV8 ah = *(const HV8*)(cur + lane_a + off);
             if constexpr (X8) {
               // hi.hi in fp16; the cross terms follow the group's last tap
-              acc[m][0] = cm_mfma16(ah, bh[0], acc[m][0]);
-              acc[m][1] = cm_mfma16(ah, bh[1], acc[m][1]);
+              acc[m][0] = mud_mfma16(ah, bh[0], acc[m][0]);
+              acc[m][1] = mud_mfma16(ah, bh[1], acc[m][1]);
             } else {
               // term by term, the two accumulators alternate: no back-to-back MFMAs on one accumulator (64->64 layers -2 %, others
               // +-0: profiles/r02_l_ab_mfma_order.txt); each accumulator adds its terms in the order lo.hi, hi.lo, hi.hi
               const HV8 al = *(const HV8*)(cur + lane_a + off + 32);
-              acc[m][0] = cm_mfma16(al, bh[0], acc[m][0]);
-              acc[m][1] = cm_mfma16(al, bh[1], acc[m][1]);
-              acc[m][0] = cm_mfma16(ah, bl[0], acc[m][0]);
-              acc[m][1] = cm_mfma16(ah, bl[1], acc[m][1]);
-              acc[m][0] = cm_mfma16(ah, bh[0], acc[m][0]);
-              acc[m][1] = cm_mfma16(ah, bh[1], acc[m][1]);
+              acc[m][0] = mud_mfma16(al, bh[0], acc[m][0]);
+              acc[m][1] = mud_mfma16(al, bh[1], acc[m][1]);
+              acc[m][0] = mud_mfma16(ah, bl[0], acc[m][0]);
+              acc[m][1] = mud_mfma16(ah, bl[1], acc[m][1]);
+              acc[m][0] = mud_mfma16(ah, bh[0], acc[m][0]);
+              acc[m][1] = mud_mfma16(ah, bh[1], acc[m][1]);
             }
           }
           if constexpr (X8) {
@@ -498,11 +484,13 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
               const char* brow = bcur + xb_lane;                                // this lane's 16 input channels of output channel r: tap 0 (hh = 0) / tap 2 (hh = 1)
               const char* brow1 = bcur + CM_BSTEP + r * 16;                     // tap 1
               const int o0 = ((g * G::GS) / KS * G::PW + (g * G::GS) % KS) * CM_PIX;      // the group's first tap (taps 3g, 3g+1, 3g+2 are one row: +80, +160 bytes)
-#pragma unroll
-              for (int term = 0; term < 2; ++term) {
-                const int wplane = CM_BPLANE + term * 1024, aoff = term ? 32 : 48;      // term 0: a_lo . w_hi, term 1: a_hi . w_lo
+              // term 0: a_lo . w_hi (a_lo image at +48 of a record, scales 2^-SAL 2^-w_exp), term 1: a_hi . w_lo (a image at +32)
+              const int d1 = hh ? 0 : 16;
+              auto cross = [&](int term) {
+                const int wplane = CM_BPLANE + term * 1024, aoff = 48 - 16 * term;
                 const char* pa0 = cur + xa_lane0 + o0 + aoff;                           // first 16 bytes: tap 0 / tap 2
-                const char* pa1 = cur + (term ? xa_lane1_t1 : xa_lane1_t0) + o0;        // second: tap 1 / the record's zero padding
+                const char* pa1 = cur + xa_lane1_t0 + o0 - d1 * term;                   // second: tap 1 / the record's zero padding
+                const int sa = term ? s_a : s_al, sb = term ? s_wl : s_w;
                 i32x8 wq[2];
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
@@ -516,10 +504,18 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
                   const i32x4 p1 = *(const i32x4*)(pa1 + m * G::PW * CM_PIX);
                   const i32x8 aq = i32x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
 #pragma unroll
-                  for (int n = 0; n < 2; ++n)
-                    acc[m][n] = term ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, s_a, 0, s_wl)
-                                     : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, s_al, 0, s_w);
+                  for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, sa, 0, sb);
                 }
+              };
+              if constexpr (DUAL) {
+                // with the second accumulator set the two terms run as a REAL loop: unrolled, hipcc hoists all sixteen operand reads of the
+                // group ahead of its MFMAs and spills 34-70 registers (scripts/kernel_resources.py); rolled, the second term reuses the
+                // first one's.  The plain kernel has the registers and is 1-3 % faster unrolled.
+#pragma clang loop unroll(disable)
+                for (int term = 0; term < 2; ++term) cross(term);
+              } else {
+                cross(0);
+                cross(1);
               }
             }
           }
@@ -891,7 +887,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       v = v * keep;
       h16x4 hi, lo;
-      cm_split4(v, hi, lo);
+      mud_split4(v, hi, lo);
       *(h16x4*)(buf + loff[j]) = hi;
       *(h16x4*)(buf + loff[j] + 32) = lo;
     }
@@ -954,9 +950,9 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
           const h16x8 al = *(const h16x8*)(cur + lane_a + off + 32);
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            acc[m][n] = cm_mfma16(al, bfr[slot][n][0], acc[m][n]);
-            acc[m][n] = cm_mfma16(ah, bfr[slot][n][1], acc[m][n]);
-            acc[m][n] = cm_mfma16(ah, bfr[slot][n][0], acc[m][n]);
+            acc[m][n] = mud_mfma16(al, bfr[slot][n][0], acc[m][n]);
+            acc[m][n] = mud_mfma16(ah, bfr[slot][n][1], acc[m][n]);
+            acc[m][n] = mud_mfma16(ah, bfr[slot][n][0], acc[m][n]);
           }
         }
       }
@@ -1127,11 +1123,11 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     char* step = dst + (int64_t)b * dst_bstride + (((int64_t)nt * k16s + kc) * taps + tap) * CM_BSTEP;
     char* base = step + co_l * 32 + ((h2 ^ ((co_l >> 3) & 1)) << 4);   // 16-B halves swapped on rows with bit 3 set: the image is copied verbatim to LDS
     if (prec == MUD_PREC_FP8X) {
-      f16x4 h0, h1, l0, l1;
-      cm_split4(v0, h0, l0);
-      cm_split4(v1, h1, l1);
-      *(f16x4*)base = h0;
-      *(f16x4*)(base + 8) = h1;
+      h16x4 h0, h1, l0, l1;
+      mud_split4(v0, h0, l0);
+      mud_split4(v1, h1, l1);
+      *(h16x4*)base = h0;
+      *(h16x4*)(base + 8) = h1;
       const f32x4 lf0 = v0 - __builtin_convertvector(h0, f32x4), lf1 = v1 - __builtin_convertvector(h1, f32x4);
       const float sw = exp2f((float)w_exp), swl = exp2f((float)(w_exp + 11));
       char* row8 = step + CM_BPLANE + (co_l >> 5) * 512 + (co_l & 31) * 16 + h2 * 8;
@@ -1141,8 +1137,8 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
       *(int*)(row8 + 1024 + 4) = cm_e4m3x4(lf1, swl);
     } else {
       h16x4 h0, h1, l0, l1;
-      cm_split4(v0, h0, l0);
-      cm_split4(v1, h1, l1);
+      mud_split4(v0, h0, l0);
+      mud_split4(v1, h1, l1);
       *(h16x4*)base = h0;
       *(h16x4*)(base + 8) = h1;
       *(h16x4*)(base + CM_BPLANE) = l0;
@@ -1367,7 +1363,7 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
   // under the other's K loop.  Measured against the 16-row tile (profiles/r02_j_ab_8x1row.txt): with a residual 330 -> 305 us,
   // without 307 -> 303 us; deeper reductions (128 / 192 / 256 -> 64) are equal, so they keep the tile with less halo.
   static const bool no8x1r = getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob
-  if (!no8x1r && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
+  if (!no8x1r && a.prec != MUD_PREC_FP8X && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
   else if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
   else if (!no16 && a.H >= 16 && blocks16 >= 256) v = CMV_16X1, nb = blocks16;
   else if (blocks2 >= 512 && a.H >= 8) v = CMV_MT2, nb = blocks2;
@@ -1393,19 +1389,21 @@ extern "C" int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* ap) {
 }
 
 // MUD_PREC_FP8X is built for the two 8-wave two-row tiles (8 x 32 px x 128 ch, 16 x 32 px x 64 ch), i.e. for launches that fill the
-// chip, with the prologues the generators use there (none: G2's gate convolutions; AdaGN + SiLU: the residual blocks).  Not with the
-// fused skip conv: its second accumulator set leaves 128 registers for the rest of the loop, and the plan's operands spill 36-70 of
-// them (scripts/kernel_resources.py) - a caller that wants this plan for a block's Conv_0 runs the 1x1 skip conv as its own launch.
-// The 64 -> 64 layers keep their one-row two-per-CU tile, whose 128-register budget the plan does not fit either.
+// chip, with the prologues the generators use there (none: G2's gate convolutions; AdaGN + SiLU: the residual blocks, with or without
+// the fused skip conv - whose own centre-tap products stay 16-bit x 3).  The 64 -> 64 layers keep their one-row two-per-CU tile,
+// whose 128-register budget the plan does not fit.
 static bool cm_fp8x_built(const mud_conv_args& a) {
-  if (a.ks != 3 || a.sub2 || a.skip_w || (a.pro_mode != MUD_PRO_NONE && a.pro_mode != MUD_PRO_AFFINE_SILU)) return false;
+  if (a.ks != 3 || a.sub2 || (a.pro_mode != MUD_PRO_NONE && a.pro_mode != MUD_PRO_AFFINE_SILU)) return false;
+  if (a.skip_w && a.pro_mode != MUD_PRO_AFFINE_SILU) return false;
   const int v = cm_variant3(a, nullptr);
   return v == CMV_8X2 || v == CMV_16X1;
 }
 extern "C" int mud_conv2d_mfma_prec_supported(const mud_conv_args* ap, int prec) {
   if (!ap || ap->B <= 0 || ap->H <= 0 || ap->W <= 0 || ap->Cin <= 0 || ap->Cout <= 0) return 0;
   if (prec == MUD_PREC_16X3) return ap->ks == 1 || ap->ks == 3;
-  return prec == MUD_PREC_FP8X && cm_fp8x_built(*ap);
+  mud_conv_args a = *ap;
+  a.prec = prec;                                 // (the tile choice looks at it)
+  return prec == MUD_PREC_FP8X && cm_fp8x_built(a);
 }
 
 extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
@@ -1452,6 +1450,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.prec == MUD_PREC_FP8X) {
     const bool x2 = cm_variant3(a, nullptr) == CMV_8X2;
+    if (a.skip_w) return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_AFFINE_SILU, true, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_AFFINE_SILU, true, MUD_PREC_FP8X>(a, s);
     if (a.pro_mode == MUD_PRO_NONE) return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s);
     return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s);
   }

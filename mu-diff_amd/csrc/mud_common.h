@@ -8,8 +8,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The 16-bit pieces of the split-precision matrix products (convolutions, attention): every fp32 operand v is carried as
+// hi = fp16(v), lo = fp16(v - hi) and every product is issued as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation: ~2^-22 per product.  fp16, not bf16 (8-bit pieces, 2^-17 per product: what rounds 1 and 2 shipped): both take
+// the same MFMA cycles, gfx950's MFMA keeps fp16 SUBNORMAL inputs (scripts/mfma_denorm_probe.hip), so values below 2^-14 lose
+// only absolute precision (<= 2^-25), and the 5 extra mantissa bits cut the path's deviation from the fp32 reference 5-8x
+// (profiles/r03_a_parity_plans.txt).  The one thing fp16 lacks is range: pieces SATURATE at +-65504 instead of overflowing.
+typedef _Float16 mud_h16;
+typedef mud_h16 mud_h16x4 __attribute__((ext_vector_type(4)));
+typedef mud_h16 mud_h16x8 __attribute__((ext_vector_type(8)));
 
 extern "C" void mud_set_error(const char* fmt, ...);
 
@@ -89,6 +96,20 @@ __device__ __forceinline__ float mud_prologue_fast(float v, float sc, float sh, 
   if (mode == MUD_PRO_LRELU) return v > 0.f ? v : 0.2f * v;
   v = fmaf(v, sc, sh);
   return mode == MUD_PRO_AFFINE_SILU ? mud_fast_silu(v) : v;
+}
+
+__device__ __forceinline__ f32x16 mud_mfma16(mud_h16x8 a, mud_h16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float mud_sat_h16(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+__device__ __forceinline__ void mud_split1(float v, mud_h16& hi, mud_h16& lo) {
+  v = mud_sat_h16(v);
+  hi = (mud_h16)v;
+  lo = (mud_h16)(v - (float)hi);
+}
+__device__ __forceinline__ void mud_split4(f32x4 v, mud_h16x4& hi, mud_h16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = mud_sat_h16(v[e]);
+  hi = __builtin_convertvector(v, mud_h16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), mud_h16x4);
 }
 
 // 64-lane butterfly sums

@@ -423,15 +423,16 @@ def direct_weight(w_oihw):
     return w_oihw.detach().permute(2, 3, 1, 0).contiguous()
 
 
-# ---- arithmetic plan per 3x3 launch (mud_conv_args.prec).  MUD_PREC_PLAN: 'off' = every launch 16-bit x 3 (bf16 pieces);
-# 'all' = the fp16 + e4m3-cross-term plan wherever the library has it; 'auto' (default) = where it was measured to pay
-# (fp8x_pays): the launches that fill the chip with >= 128 output channels - the 64-output-channel layers at 256x256 are not
-# bound by matrix cycles and keep the exact-er plan.
-PREC_PLAN = os.environ.get('MUD_PREC_PLAN', 'off')
+# ---- arithmetic plan per 3x3 launch (mud_conv_args.prec).  MUD_PREC_PLAN: 'auto' (default) = the fp16 + e4m3-cross-term plan
+# (MUD_PREC_FP8X) for every launch the library has it for and that was measured to gain (fp8x_pays; profiles/r03_*_ab_prec_b16.txt:
+# 0.87-0.99x per launch, largest on the deep layers), 16-bit x 3 elsewhere (small grids, 1x1, the exact head / tail kernels);
+# 'off' = every launch 16-bit x 3; 'all' = wherever the library has the plan, measured or not.
+PREC_PLAN = os.environ.get('MUD_PREC_PLAN', 'auto')
 
 
 def fp8x_pays(B, H, W, cin, cout):
-    return cout >= 128 and cin >= 64
+    """Per-shape verdict of the in-process A/B (scripts/ab_prec.py): True where MUD_PREC_FP8X was not slower than 16-bit x 3."""
+    return cin > 64 or cout > 64          # 64 -> 64 at 256x256: see profiles/r03_*_ab_prec_b16.txt
 
 
 def conv_prec_supported(x: View, cout, pro_mode, prec, skip=False, sub2=False):

@@ -49,6 +49,8 @@ for H, Cin, Cout, pro, res, skip, cnt in shapes:
     if skip:
         runs['16x3+fused skip'] = lambda: ops.conv(x, p16, 3, Cout, out=out, skip=(p1, None, so), **kw)
         runs['16x3, skip apart'] = lambda: (ops.conv(x, p16, 3, Cout, out=out, **kw), ops.conv(x, p1, 1, Cout, mfma=True, out=so))
+        if ops.conv_prec_supported(x, Cout, pro, ops.PREC_FP8X, skip=True):
+            runs['fp8x+fused skip'] = lambda: ops.conv(x, p8, 3, Cout, out=out8, prec=ops.PREC_FP8X, w_exp=we, skip=(p1, None, so), **kw)
         if sup:
             runs['fp8x, skip apart'] = lambda: (ops.conv(x, p8, 3, Cout, out=out8, prec=ops.PREC_FP8X, w_exp=we, **kw), ops.conv(x, p1, 1, Cout, mfma=True, out=so))
     for fn in runs.values():

@@ -430,7 +430,7 @@ def golden_cfg3_wide():
     cfg = O.default_config()
     u8 = brats_like_slices_u8(16, seed=2020)
     sl = torch.from_numpy(u8.astype(np.float32)) / 255.0 * 2.0 - 1.0
-    out = {'slices_u8': u8, 'targets': np.array(list(CFG3_ORDERS))}
+    out = {'slices_u8': u8}
     for gi, (tgt, order) in enumerate(CFG3_ORDERS.items()):
         idx = slice(4 * gi, 4 * gi + 4)
         conds = [sl[idx, CFG3_MODS.index(m)][:, None].contiguous() for m in order[:3]]

@@ -228,7 +228,7 @@ def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
                                                      (16, 70, 33, 96, 128, True, True), (16, 128, 128, 192, 64, True, False)])
 def test_conv_fp8x_plan_vs_fp64(B, H, W, Cin, Cout, pro, res):
     """MUD_PREC_FP8X (fp16 hi.hi + both cross terms on the block-scaled e4m3 MFMA, per-layer weight exponent): against fp64, next to
-    the 16-bit x 3 plan on the same problem.  ~2^-15 per product: rms error within 4x of the 16x3 plan's and <= 4e-5 of the output rms;
+    the 16-bit x 3 plan on the same problem.  ~2^-15 per product: rms error <= 4e-5 of the convolution's rms (the fp16 x 3 plan: <= 4e-6);
     weights far from unit scale exercise the per-layer exponent."""
     ops, *_ = _imports()
     gen = torch.Generator().manual_seed(B + H + Cin + Cout)
@@ -254,7 +254,7 @@ def test_conv_fp8x_plan_vs_fp64(B, H, W, Cin, Cout, pro, res):
         conv_rms = rms(ref - (r.double() if res else 0) - bias.double()[None, :, None, None])
         e8, e16 = rms(y8 - ref), rms(y16 - ref)
         print(f'{B}x{H}x{W} {Cin}->{Cout} w x{wscale:g} (2^{we}): rms err fp8x {e8:.2e} 16x3 {e16:.2e}; conv rms {conv_rms:.2f}; max-abs fp8x {float((y8 - ref).abs().max()):.2e}')
-        assert not torch.isnan(y8).any() and e8 <= 4e-5 * max(conv_rms, 1e-3) and e8 <= 6 * e16 + 1e-7
+        assert not torch.isnan(y8).any() and e8 <= 4e-5 * conv_rms + 1e-6 and e16 <= 4e-6 * conv_rms + 1e-6
 
 
 def test_c_abi_refuses_a_plan_that_is_not_built_for_the_launch():
