@@ -267,7 +267,9 @@ def test_c_abi_refuses_a_plan_that_is_not_built_for_the_launch():
     x = ops.View(torch.randn(1, 16, 16, 64, device=DEV), 1, 16, 16, 64)
     assert not ops.conv_prec_supported(x, 64, ops.PRO_AFFINE_SILU, ops.PREC_FP8X)
     big = ops.View(torch.randn(4, 128, 128, 128, device=DEV), 4, 128, 128, 128)
-    assert ops.conv_prec_supported(big, 128, ops.PRO_AFFINE_SILU, ops.PREC_FP8X) and not ops.conv_prec_supported(big, 128, ops.PRO_AFFINE_SILU, ops.PREC_FP8X, skip=True)
+    assert ops.conv_prec_supported(big, 128, ops.PRO_AFFINE_SILU, ops.PREC_FP8X) and ops.conv_prec_supported(big, 128, ops.PRO_AFFINE_SILU, ops.PREC_FP8X, skip=True)
+    assert not ops.conv_prec_supported(big, 128, ops.PRO_NONE, ops.PREC_FP8X, skip=True)        # the fused skip conv is the residual blocks' (AdaGN + SiLU prologue)
+    assert not ops.conv_prec_supported(big, 128, ops.PRO_AFFINE, ops.PREC_FP8X)
     w = torch.randn(64, 64, 3, 3, device=DEV)
     with pytest.raises(mudiff_hip.MudiffHipError, match='MUD_PREC_FP8X is not built'):
         ops.conv(x, ops.pack_conv_weight(w, prec=ops.PREC_FP8X, w_exp=3), 3, 64, mfma=True, prec=ops.PREC_FP8X, w_exp=3)
@@ -369,6 +371,15 @@ def test_conv_with_fused_skip_conv(B, H, W, Cin, Cout):
     e1, e2 = maxdiff(out.to_nchw(), ref), maxdiff(skip.to_nchw(), ref_s)
     print(f'fused skip conv {B}x{H}x{W} {Cin}->{Cout}: 3x3 {e1:.2e}, 1x1 skip {e2:.2e} vs fp64')
     assert e1 <= 1e-4 and e2 <= 1e-4
+    if ops.conv_prec_supported(xv, Cout, ops.PRO_AFFINE_SILU, ops.PREC_FP8X, skip=True):
+        # the same launch under the fp16 + e4m3-cross-term plan (the skip conv's own products stay fp16 x 3: same bits as above)
+        we = ops.fp8x_weight_exponent(w)
+        out8, skip8 = ops.View.empty(B, H, W, Cout, DEV), ops.View.empty(B, H, W, Cout, DEV)
+        ops.conv(xv, ops.pack_conv_weight(g(w), prec=ops.PREC_FP8X, w_exp=we), 3, Cout, mfma=True, pro=pro, bias=g(bias), bias2=g(b2), out=out8,
+                 skip=(w2p, g(bias_s), skip8), prec=ops.PREC_FP8X, w_exp=we)
+        e8 = maxdiff(out8.to_nchw(), ref)
+        print(f'   under MUD_PREC_FP8X: 3x3 {e8:.2e} vs fp64')
+        assert e8 <= 3e-4 and torch.equal(skip8.to_nchw(), skip.to_nchw())
     assert maxdiff(out.stats[..., 0], ref.sum(dim=(2, 3))) <= 2e-6 * float(ref.abs().sum(dim=(2, 3)).max())
     if ops.conv3x3_would_split_k(xv, Cout):                         # the fused launch split over K: the same bits whoever arrives last
         first, first_s = out.to_nchw().clone(), skip.to_nchw().clone()
