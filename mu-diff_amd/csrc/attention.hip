@@ -552,6 +552,7 @@ static int at_launch_pair(const float* qkv, int B, int N, int ld, float scale, f
       mud_set_error("mud_attention: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
+    attr_once.ok();
   }
   const int ntiles = (int)mud_cdiv(N, 32);
   const int ns = ws ? at_splits(B, N) : 1;
@@ -576,6 +577,7 @@ static int at_launch(const float* qkv, int B, int N, int ld, float scale, float*
       mud_set_error("mud_attention: cannot reserve %d B of LDS: %s", G::LDS_BYTES, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
+    attr_once.ok();
   }
   const int ntiles = (int)mud_cdiv(N, 32);
   const int ns = ws ? at_splits(B, N) : 1;

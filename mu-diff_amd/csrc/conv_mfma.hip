@@ -1273,6 +1273,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
       mud_set_error("mud_conv2d_mfma: cannot reserve %d B of LDS: %s", G::LDS_MAX, hipGetErrorString(e));
       return MUD_ERR_LAUNCH;
     }
+    attr_once.ok();
   }
   const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN * WN);
   const int lds = G::lds_bytes(a.gn_sums ? a.Cin : 0);

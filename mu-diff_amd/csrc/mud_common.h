@@ -41,12 +41,17 @@ extern "C" void mud_set_error(const char* fmt, ...);
 // current device, so a process that drives several GPUs must repeat it on each.
 struct mud_attr_once {
   bool done[64] = {};
-  bool need() {
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-    if (done[d]) return false;
-    done[d] = true;      // benign race: two threads may both set the attribute
-    return true;
+  int dev = -1;
+  bool need() {          // true: the caller must (re)set the attribute on the current device, then call ok() once that succeeded
+    dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      dev = -1;
+      return true;
+    }
+    return !done[dev];   // benign race: two threads may both set the attribute
+  }
+  void ok() {            // a FAILED hipFuncSetAttribute is retried by the next call instead of being remembered as done
+    if (dev >= 0) done[dev] = true;
   }
 };
 

@@ -336,15 +336,40 @@ FUSE_SKIP = os.environ.get('MUD_FUSE_SKIP', '1') != '0'     # A/B knob: 0 = the 
 
 
 _SPLITK_COUNTERS = {}
+_SPLITK_OWNED = []        # innermost `own_splitk_counters` buffer, if any
+
+
+def new_splitk_counters(device):
+    return torch.zeros(4096, device=device, dtype=torch.int32)
+
+
+class own_splitk_counters:
+    """Context: the split-K launches issued inside use THIS counter array.  A captured hipGraph can be replayed on any stream, and
+    two graphs replayed concurrently (two samplers on two streams) must not share arrival counters - a tile would be reduced early
+    or never - so every GraphSampler captures with an array of its own instead of the per-(device, stream) one below."""
+
+    def __init__(self, buf):
+        self.buf = buf
+
+    def __enter__(self):
+        _SPLITK_OWNED.append(self.buf)
+        return self.buf
+
+    def __exit__(self, *exc):
+        _SPLITK_OWNED.pop()
+        return False
 
 
 def splitk_counters(device):
-    """Arrival counters of the in-launch split-K reduction (mud_conv_args.splitk_counters): one zeroed array per (device, stream) -
-    launches on one stream are ordered, and every launch leaves the counters at zero."""
+    """Arrival counters of the in-launch split-K reduction (mud_conv_args.splitk_counters): the array of the enclosing
+    `own_splitk_counters` context (graph capture), else one zeroed array per (device, stream) - launches on one stream are ordered,
+    and every launch leaves the counters at zero."""
+    if _SPLITK_OWNED and _SPLITK_OWNED[-1].device == torch.device(device):
+        return _SPLITK_OWNED[-1]
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _SPLITK_COUNTERS.get(key)
     if buf is None:
-        buf = _SPLITK_COUNTERS[key] = torch.zeros(4096, device=device, dtype=torch.int32)
+        buf = _SPLITK_COUNTERS[key] = new_splitk_counters(device)
     return buf
 
 

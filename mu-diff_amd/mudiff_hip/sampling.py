@@ -175,7 +175,11 @@ class GraphSampler:
         self.noise = torch.zeros(B, 1, H, W, **f)
         self.t = torch.zeros(B, dtype=torch.int64, device=dev)
         self.graph = None
-        self._capture(warmup)
+        # arrival counters of the split-K convolutions captured below: this sampler's own (its graphs may be replayed on any
+        # stream, next to another sampler's)
+        self._splitk = ops.new_splitk_counters(dev)
+        with ops.own_splitk_counters(self._splitk):
+            self._capture(warmup)
 
     def _step(self):
         x01 = self.g1(self.x, self.c1, self.c2, self.c3, self.t, self.z)

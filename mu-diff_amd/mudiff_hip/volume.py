@@ -209,9 +209,12 @@ def predict_slices(args, gen1, gen2, cond_stacks, device, batch_size=32, x_inits
     T = int(args.num_timesteps)
     bs = min(int(batch_size), n)
     if sampler is not None:
+        if not use_graph:
+            raise ValueError('predict_slices: sampler= is a captured hipGraph; it cannot be combined with use_graph=False')
         if (sampler.H, sampler.W) != (size, size) or sampler.g1 is not gen1 or sampler.g2 is not gen2:
             raise ValueError('predict_slices: the sampler was built for other generators or another image size')
-        bs = sampler.B                           # (a short last batch is padded to the captured shape either way)
+        bs = sampler.B                           # the captured batch size wins over batch_size (a short last batch is padded either way;
+                                                 # seeded draws are made per slice below, so the result does not depend on it)
     elif use_graph:
         sampler = S.GraphSampler(coef, gen1, gen2, args, bs, size, size, device)
     out = torch.empty(n, size, size, device=device, dtype=torch.float32)
@@ -220,16 +223,20 @@ def predict_slices(args, gen1, gen2, cond_stacks, device, batch_size=32, x_inits
         t = t[lo:hi].to(device)
         return t if hi - lo == bs else torch.cat([t, t[-1:].expand(bs - (hi - lo), *t.shape[1:])], 0)
 
+    if gen is not None and zs is None:
+        # seeded run: every slice's draws come from its GLOBAL index (one pass over the generator for the whole volume), so the
+        # same seed gives the same volume whatever the batch size or the reused sampler's captured shape (161 slices: 200 MB)
+        if x_inits is None:
+            x_inits = torch.randn(n, 1, size, size, device=device, generator=gen)
+        zs = [torch.randn(n, args.nz, device=device, generator=gen) for _ in range(T)]
+        noises = [torch.randn(n, 1, size, size, device=device, generator=gen) for _ in range(T)]
     for lo in range(0, n, bs):
         hi = min(lo + bs, n)
         c1, c2, c3 = (padded(c, lo, hi) for c in conds)
-        x0 = padded(x_inits, lo, hi) if x_inits is not None else torch.randn(bs, 1, size, size, device=device, generator=gen)
+        x0 = padded(x_inits, lo, hi) if x_inits is not None else torch.randn(bs, 1, size, size, device=device)
         kw = {}
         if zs is not None:
             kw = dict(zs=[padded(z, lo, hi) for z in zs], noises=[padded(e, lo, hi) for e in noises])
-        elif gen is not None:
-            kw = dict(zs=[torch.randn(bs, args.nz, device=device, generator=gen) for _ in range(T)],
-                      noises=[torch.randn(bs, 1, size, size, device=device, generator=gen) for _ in range(T)])
         if sampler is not None:
             fake = sampler.sample(c1, c2, c3, x0, T, **kw)
         else:

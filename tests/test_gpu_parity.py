@@ -795,6 +795,32 @@ def test_graph_sampler_matches_eager_and_batches():
     assert maxdiff(eager, ref) <= 1e-3
 
 
+def test_two_samplers_replayed_concurrently_have_their_own_splitk_counters():
+    """a captured graph can be replayed on any stream; two one-slice samplers (whose 64x64 convolutions split over K and
+    reduce in-launch through arrival counters) replayed side by side on two streams must not share a counter array."""
+    ops, S, *_ = _imports()
+    cfg = O.default_config()
+    g1, g2 = _build(cfg)
+    coef = S.Posterior_Coefficients(cfg, DEV)
+    sa, sb = (S.GraphSampler(coef, g1, g2, cfg, 1, 256, 256, DEV) for _ in range(2))
+    assert sa._splitk.data_ptr() != sb._splitk.data_ptr()
+    conds = [g(c) for c in demo_conds()]
+    xa, zs_a, ns_a = sampler_inputs(cfg, 1, seed_x=42)
+    xb, zs_b, ns_b = sampler_inputs(cfg, 1, seed_x=77)
+    run = lambda sm, x, zs, ns: sm.sample(*conds, g(x), 2, zs=[g(z) for z in zs[:2]], noises=[g(n) for n in ns[:2]])
+    ref_a, ref_b = run(sa, xa, zs_a, ns_a).clone(), run(sb, xb, zs_b, ns_b).clone()
+    torch.cuda.synchronize()
+    st_a, st_b = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(st_a):
+            out_a = run(sa, xa, zs_a, ns_a)
+        with torch.cuda.stream(st_b):
+            out_b = run(sb, xb, zs_b, ns_b)
+        torch.cuda.synchronize()
+        assert maxdiff(out_a, ref_a) <= 2e-5 and maxdiff(out_b, ref_b) <= 2e-5
+    assert int(sa._splitk.abs().sum()) == 0 and int(sb._splitk.abs().sum()) == 0      # every launch leaves its counters at zero
+
+
 def test_loop_cache_changes_nothing():
     """sample_from_model / GraphSampler hoist what depends on the condition images alone out of the reverse loop
     (begin_loop_cache): same images as plain per-step forward calls (which never cache), and a second sampling run with OTHER
