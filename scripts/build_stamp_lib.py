@@ -24,7 +24,7 @@ def sub(old, new):
 sub("  const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles",
     "  const int wm = wave % WM, wn = wave / WM;\n  STAMP(0);")
 sub("  store_a(kc0, smem + (kc0 & 1) * G::BUF);\n  __syncthreads();", "  store_a(kc0, smem + (kc0 & 1) * G::BUF);\n  __syncthreads();\n  STAMP(1); STAMP(58);")
-sub("    if (pre_res && kc == kc_pre) prefetch_res();", "    STAMP(2 + kc);\n    if (pre_res && kc == kc_pre) prefetch_res();")
+sub("    const bool more = kc + 1 < nchunks;\n#pragma unroll\n    for (int g = 0; g < G::NG; ++g) {", "    const bool more = kc + 1 < nchunks;\n    STAMP(2 + kc);\n#pragma unroll\n    for (int g = 0; g < G::NG; ++g) {")
 sub("      __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves",
     "      if (kc == 2) STAMP(40 + 2 * g);\n      __syncthreads();\n      if (kc == 2) STAMP(41 + 2 * g);")
 sub("  // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]", "  STAMP(60); STAMP(59);\n  // ---- epilogue")
@@ -38,7 +38,9 @@ try:
     subprocess.check_call(['make', '-C', CSRC])
     subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-fPIC', '-std=c++17', '--offload-arch=gfx950', '-Wno-unused-function', '-c', src,
                            '-o', '/tmp/_conv_stamp.o'])
-    objs = [os.path.join(CSRC, o) for o in ('elementwise.o', 'groupnorm.o', 'dense.o', 'conv_direct.o', 'fir.o', 'attention.o', 'api.o')]
+    objs = [os.path.join(CSRC, o) for o in ('elementwise.o', 'groupnorm.o', 'dense.o', 'conv_direct.o', 'fir.o', 'attention.o')]
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O2', '-fPIC', '-std=c++17', '-DMUD_BUILD_FLAGS="stamps"', '-c', os.path.join(CSRC, 'api.cpp'), '-o', '/tmp/_api_stamp.o'])
+    objs.append('/tmp/_api_stamp.o')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '/tmp/_conv_stamp.o', '-o',
                            os.path.join(out, 'libstamp.so')])
 finally:
