@@ -965,6 +965,13 @@ def test_volume_slices_batched_vs_per_slice_oracle(use_graph):
         other, _ = _build(cfg, seed=10)
         with pytest.raises(ValueError):
             V.predict_slices(cfg, other, g2, stacks, DEV, x_inits=x_inits, zs=zs, noises=noises, sampler=smp)
+        with pytest.raises(ValueError):      # a captured sampler cannot be combined with use_graph=False (used to be ignored silently)
+            V.predict_slices(cfg, g1, g2, stacks, DEV, x_inits=x_inits, zs=zs, noises=noises, sampler=smp, use_graph=False)
+        # a SEEDED run draws per slice by global index: the same seed gives the same volume whatever the batching
+        # (batch 2 through the reused sampler, batch 5 and batch 3 through samplers of their own)
+        seeded = [V.predict_slices(cfg, g1, g2, stacks, DEV, batch_size=bs, seed=123, sampler=sm) for bs, sm in ((2, smp), (5, None), (3, None))]
+        assert max(float(np.abs(v - seeded[0]).max()) for v in seeded[1:]) <= 1e-4
+        assert float(np.abs(V.predict_slices(cfg, g1, g2, stacks, DEV, batch_size=2, seed=124, sampler=smp) - seeded[0]).max()) > 1e-3
 
 
 def test_predict_volume_end_to_end_nifti(tmp_path):
