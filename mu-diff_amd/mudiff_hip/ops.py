@@ -449,15 +449,18 @@ def direct_weight(w_oihw):
 
 
 # ---- arithmetic plan per 3x3 launch (mud_conv_args.prec).  MUD_PREC_PLAN: 'auto' (default) = the fp16 + e4m3-cross-term plan
-# (MUD_PREC_FP8X) for every launch the library has it for and that was measured to gain (fp8x_pays; profiles/r03_*_ab_prec_b16.txt:
-# 0.87-0.99x per launch, largest on the deep layers), 16-bit x 3 elsewhere (small grids, 1x1, the exact head / tail kernels);
-# 'off' = every launch 16-bit x 3; 'all' = wherever the library has the plan, measured or not.
+# (MUD_PREC_FP8X) for every launch the library has it for (fp8x_pays), fp16 x 3 elsewhere (small grids, 1x1, the exact head / tail
+# kernels); 'off' = every launch fp16 x 3; 'all' = wherever the library has the plan, whatever fp8x_pays says.
 PREC_PLAN = os.environ.get('MUD_PREC_PLAN', 'auto')
 
 
 def fp8x_pays(B, H, W, cin, cout):
-    """Per-shape verdict of the in-process A/B (scripts/ab_prec.py): True where MUD_PREC_FP8X was not slower than 16-bit x 3."""
-    return cin > 64 or cout > 64          # 64 -> 64 at 256x256: see profiles/r03_*_ab_prec_b16.txt
+    """Should a launch the library has MUD_PREC_FP8X for take it?  Per launch in isolation (scripts/ab_prec.py, batch 16,
+    profiles/r03_b_ab_prec_b16.txt) the plan is 0.87-0.99x on every shape except the 64 -> 64 layers at 256x256 (1.07 / 1.15x on
+    the two-row tile they need under it); in the whole bench line at batch 32, alternated on one box, taking it for those too
+    is +2 % (98.9 / 98.6 against 97.1 / 96.3 slices/s, profiles/r03_d_plan_alternation.txt) - the chip is clock-limited under
+    this kernel, and matrix cycles saved in one launch come back as clock for the next - so the whole-path measurement decides."""
+    return True
 
 
 def conv_prec_supported(x: View, cout, pro_mode, prec, skip=False, sub2=False):
