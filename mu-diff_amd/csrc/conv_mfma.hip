@@ -507,10 +507,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
                   for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, wq[n], acc[m][n], 0, 0, 0, sa, 0, sb);
                 }
               };
-              if constexpr (DUAL) {
-                // with the second accumulator set the two terms run as a REAL loop: unrolled, hipcc hoists all sixteen operand reads of the
-                // group ahead of its MFMAs and spills 34-70 registers (scripts/kernel_resources.py); rolled, the second term reuses the
-                // first one's.  The plain kernel has the registers and is 1-3 % faster unrolled.
+              if constexpr (DUAL || MT == 1) {
+                // with the second accumulator set (256 registers) and in the one-row tile (128 registers, two workgroups per CU) the two
+                // terms run as a REAL loop: unrolled, hipcc hoists all sixteen operand reads of the group ahead of its MFMAs and spills
+                // 34-70 registers (scripts/kernel_resources.py); rolled, the second term reuses the first one's.  The plain two-row kernels
+                // have the registers and are 1-3 % faster unrolled.
 #pragma clang loop unroll(disable)
                 for (int term = 0; term < 2; ++term) cross(term);
               } else {
@@ -1364,7 +1365,7 @@ static int cm_variant3(const mud_conv_args& a, int64_t* blocks) {
   // under the other's K loop.  Measured against the 16-row tile (profiles/r02_j_ab_8x1row.txt): with a residual 330 -> 305 us,
   // without 307 -> 303 us; deeper reductions (128 / 192 / 256 -> 64) are equal, so they keep the tile with less halo.
   static const bool no8x1r = getenv("MUD_CONV_NO8X1R") != nullptr;   // A/B knob
-  if (!no8x1r && a.prec != MUD_PREC_FP8X && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
+  if (!no8x1r && !a.skip_w && ntiles == 1 && a.Cin <= 64 && a.H >= 8 && blocks2 >= 512) v = CMV_8X1R, nb = blocks2;
   else if (ntiles % 2 == 0 && a.H >= 8 && blocks8 >= 256) v = CMV_8X2, nb = blocks8;
   else if (!no16 && a.H >= 16 && blocks16 >= 256) v = CMV_16X1, nb = blocks16;
   else if (blocks2 >= 512 && a.H >= 8) v = CMV_MT2, nb = blocks2;
@@ -1389,15 +1390,14 @@ extern "C" int64_t mud_conv2d_mfma_splitk_bytes(const mud_conv_args* ap) {
   return ns > 1 ? cm_slab_bytes(ns, blocks, tile_words) : 0;
 }
 
-// MUD_PREC_FP8X is built for the two 8-wave two-row tiles (8 x 32 px x 128 ch, 16 x 32 px x 64 ch), i.e. for launches that fill the
-// chip, with the prologues the generators use there (none: G2's gate convolutions; AdaGN + SiLU: the residual blocks, with or without
-// the fused skip conv - whose own centre-tap products stay 16-bit x 3).  The 64 -> 64 layers keep their one-row two-per-CU tile,
-// whose 128-register budget the plan does not fit.
+// MUD_PREC_FP8X is built for the 8-wave tiles (8 x 32 px x 128 ch, 16 x 32 px x 64 ch, and the one-row 8 x 32 px x 64 ch tile of the
+// 64 -> 64 layers), i.e. for launches that fill the chip, with the prologues the generators use there (none: G2's gate / fusion
+// convolutions; AdaGN + SiLU: the residual blocks, with or without the fused skip conv - whose own centre-tap products stay 16-bit x 3).
 static bool cm_fp8x_built(const mud_conv_args& a) {
   if (a.ks != 3 || a.sub2 || (a.pro_mode != MUD_PRO_NONE && a.pro_mode != MUD_PRO_AFFINE_SILU)) return false;
   if (a.skip_w && a.pro_mode != MUD_PRO_AFFINE_SILU) return false;
   const int v = cm_variant3(a, nullptr);
-  return v == CMV_8X2 || v == CMV_16X1;
+  return v == CMV_8X2 || v == CMV_16X1 || v == CMV_8X1R;
 }
 extern "C" int mud_conv2d_mfma_prec_supported(const mud_conv_args* ap, int prec) {
   if (!ap || ap->B <= 0 || ap->H <= 0 || ap->W <= 0 || ap->Cin <= 0 || ap->Cout <= 0) return 0;
@@ -1450,7 +1450,9 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
   if (a.B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
   if (a.prec == MUD_PREC_FP8X) {
-    const bool x2 = cm_variant3(a, nullptr) == CMV_8X2;
+    const int v8 = cm_variant3(a, nullptr);
+    if (v8 == CMV_8X1R) return a.pro_mode == MUD_PRO_NONE ? cm_launch_pro<3, 1, 8, 1, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 1, 8, 1, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s);
+    const bool x2 = v8 == CMV_8X2;
     if (a.skip_w) return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_AFFINE_SILU, true, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_AFFINE_SILU, true, MUD_PREC_FP8X>(a, s);
     if (a.pro_mode == MUD_PRO_NONE) return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s);
     return x2 ? cm_launch_pro<3, 2, 4, 2, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 2, 8, 1, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s);

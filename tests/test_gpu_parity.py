@@ -225,7 +225,8 @@ def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,pro,res', [(8, 64, 64, 256, 256, True, True), (4, 128, 128, 128, 128, True, False), (1, 256, 256, 192, 384, False, False),
-                                                     (16, 70, 33, 96, 128, True, True), (16, 128, 128, 192, 64, True, False)])
+                                                     (16, 70, 33, 96, 128, True, True), (16, 128, 128, 192, 64, True, False),
+                                                     (8, 128, 128, 64, 64, True, True), (8, 128, 128, 64, 64, False, False)])
 def test_conv_fp8x_plan_vs_fp64(B, H, W, Cin, Cout, pro, res):
     """MUD_PREC_FP8X (fp16 hi.hi + both cross terms on the block-scaled e4m3 MFMA, per-layer weight exponent): against fp64, next to
     the 16-bit x 3 plan on the same problem.  ~2^-15 per product: rms error <= 4e-5 of the convolution's rms (the fp16 x 3 plan: <= 4e-6);
