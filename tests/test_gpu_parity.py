@@ -258,6 +258,30 @@ def test_conv_fp8x_plan_vs_fp64(B, H, W, Cin, Cout, pro, res):
         assert not torch.isnan(y8).any() and e8 <= 4e-5 * conv_rms + 1e-6 and e16 <= 4e-6 * conv_rms + 1e-6
 
 
+def test_fp8x_plan_degrades_gracefully_out_of_range():
+    """Activations outside the e4m3 images' range (|a| > 112 or < 5e-4) only lose their CROSS terms (those products fall back to
+    one 11-bit piece: <= 2^-10 relative), values beyond fp16's range saturate at +-65504; nothing becomes NaN or inf."""
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(5)
+    B, H, Cin, Cout = 4, 128, 128, 128
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    we = ops.fp8x_weight_exponent(w)
+    w8 = ops.pack_conv_weight(g(w), prec=ops.PREC_FP8X, w_exp=we)
+    for scale, tol in ((300.0, 2.0 ** -10), (1e-5, 2.0 ** -10), (1.0, 4e-5)):
+        x = torch.randn(B, Cin, H, H, generator=gen) * scale
+        xv = ops.View.from_nchw(g(x))
+        assert ops.conv_prec_supported(xv, Cout, ops.PRO_NONE, ops.PREC_FP8X)
+        y = ops.conv(xv, w8, 3, Cout, mfma=True, prec=ops.PREC_FP8X, w_exp=we).to_nchw().cpu().double()
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+        rel = float((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        print(f'fp8x plan, inputs x{scale:g}: rms error {rel:.2e} of the output rms (allowed {tol:.1e})')
+        assert torch.isfinite(y).all() and rel <= tol
+    x = torch.full((B, Cin, H, H), 1e6)
+    y = ops.conv(ops.View.from_nchw(g(x)), w8, 3, Cout, mfma=True, prec=ops.PREC_FP8X, w_exp=we).to_nchw().cpu()
+    y16 = ops.conv(ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), 3, Cout, mfma=True).to_nchw().cpu()
+    assert torch.isfinite(y).all() and torch.isfinite(y16).all()          # saturated at 65504, not inf / NaN (both plans)
+
+
 def test_c_abi_refuses_a_plan_that_is_not_built_for_the_launch():
     """Weights packed for MUD_PREC_FP8X cannot be read by another plan, so mud_conv2d_mfma must fail loudly (nothing launched)
     where the plan does not exist: small grids, the fused skip conv, 1x1 kernels."""
