@@ -456,10 +456,9 @@ PREC_PLAN = os.environ.get('MUD_PREC_PLAN', 'auto')
 
 def fp8x_pays(B, H, W, cin, cout):
     """Should a launch the library has MUD_PREC_FP8X for take it?  Per launch in isolation (scripts/ab_prec.py, batch 16,
-    profiles/r03_b_ab_prec_b16.txt) the plan is 0.87-0.99x on every shape except the 64 -> 64 layers at 256x256 (1.07 / 1.15x on
-    the two-row tile they need under it); in the whole bench line at batch 32, alternated on one box, taking it for those too
-    is +2 % (98.9 / 98.6 against 97.1 / 96.3 slices/s, profiles/r03_d_plan_alternation.txt) - the chip is clock-limited under
-    this kernel, and matrix cycles saved in one launch come back as clock for the next - so the whole-path measurement decides."""
+    profiles/r03_g_ab_prec_b16.txt) the plan is 0.86-0.99x of the fp16 x 3 launch on every shape it is built for (the 64 -> 64
+    layers at 256x256 included, on their one-row tile), and the whole bench line alternated on one box agrees
+    (profiles/r03_d_plan_alternation.txt): no shape is excluded.  The hook stays for shapes a later measurement finds to lose."""
     return True
 
 
