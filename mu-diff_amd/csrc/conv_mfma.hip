@@ -143,6 +143,51 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
+// One float4 of raw activations -> its LDS pieces (prologue, hi / lo split, e4m3 images).  SCALAR f32 arithmetic on purpose: beside
+// MFMAs a packed f32 instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32) costs ~4x two plain ones (MI355X_MICROARCH.md, constants
+// table, "price of one filler beside MFMAs"), and hipcc packs every float4 expression and every pair of adjacent scalar ones it can
+// find - so the staging code works on elements and this file is compiled with -fno-slp-vectorize (csrc/Makefile).
+template <int PRO, bool X8>
+__device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, const f32x4& sh, float keep, h16x4& hi, h16x4& lo, int& a8, int& al8) {
+  f32x4 v, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = rw[e];
+    if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
+      x = __builtin_fmaf(x, sc[e], sh[e]);
+      if (PRO == MUD_PRO_AFFINE_SILU) x = cm_fast_silu(x);
+    } else if (PRO == MUD_PRO_LRELU) {
+      x = x > 0.f ? x : 0.2f * x;
+    }
+    v[e] = mud_sat_h16(x * keep);              // zero padding stays zero; fp16 pieces saturate instead of overflowing
+  }
+  hi = __builtin_convertvector(v, h16x4);      // (2 x v_cvt_pk_f16_f32: a conversion, not packed arithmetic)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) l[e] = v[e] - (float)hi[e];
+  if constexpr (X8) {
+    float t[4], u[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] = __builtin_amdgcn_fmed3f(v[e] * (float)(1 << CM_X_SA), -448.0f, 448.0f);
+      u[e] = __builtin_amdgcn_fmed3f(l[e] * (float)(1 << CM_X_SAL), -448.0f, 448.0f);
+    }
+    a8 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false), true);
+    al8 = __builtin_amdgcn_cvt_pk_fp8_f32(u[2], u[3], __builtin_amdgcn_cvt_pk_fp8_f32(u[0], u[1], 0, false), true);
+  } else {
+    lo = __builtin_convertvector(l, h16x4);
+  }
+}
+// v = hi + lo in fp16 pieces, element by element (the scalar twin of mud_split4, for the same reason)
+__device__ __forceinline__ void cm_split4s(const f32x4& rw, float keep, h16x4& hi, h16x4& lo) {
+  f32x4 v, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = mud_sat_h16(rw[e] * keep);
+  hi = __builtin_convertvector(v, h16x4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) l[e] = v[e] - (float)hi[e];
+  lo = __builtin_convertvector(l, h16x4);
+}
+
 // DUAL: the launch also produces the residual block's 1x1 skip convolution of the RAW input (reference layerspp.py:320-321,
 // `x = self.Conv_2(x)`) from the same staged tile - skip_out = skip_w * x + skip_bias - so that x is read from HBM once instead
 // of twice (the skip convs are pure HBM streams: 3.3-4.8 TB/s, 8 % of a forward) at the price of one more tap's MFMAs.
@@ -264,34 +309,21 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
       if (j < j0 || j >= j1) continue;
-      f32x4 v = raw[j];
-      if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
-        v = v * psc_r + psh_r;
-        if (PRO == MUD_PRO_AFFINE_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
-        }
-      } else if (PRO == MUD_PRO_LRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-      }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
-      v = v * keep;
       HV4 hi, lo;
-      mud_split4(v, hi, lo);
+      int a8 = 0, al8 = 0;
+      cm_stage4<PRO, X8>(raw[j], psc_r, psh_r, keep, hi, lo, a8, al8);
       *(HV4*)(buf + loff[j]) = hi;
       if constexpr (X8) {                       // (loff holds record + 8 q)
-        const f32x4 lof = v - __builtin_convertvector(hi, f32x4);                            // exact in fp32 (|v| <= 65504 here or saturated: see cm_split4)
-        *(int*)(buf + loff[j] + 32 - q * 4) = cm_e4m3x4(v, (float)(1 << CM_X_SA));         // record + 32 + 4 q
-        *(int*)(buf + loff[j] + 48 - q * 4) = cm_e4m3x4(lof, (float)(1 << CM_X_SAL));      // record + 48 + 4 q
+        *(int*)(buf + loff[j] + 32 - q * 4) = a8;          // record + 32 + 4 q
+        *(int*)(buf + loff[j] + 48 - q * 4) = al8;         // record + 48 + 4 q
       } else {
         *(HV4*)(buf + loff[j] + 32) = lo;
       }
       if (DUAL) {                               // the RAW value of the tile's centre pixels: A operand of the 1x1 skip conv (always 16-bit x 3)
         if (loff2[j] >= 0) {
-          const f32x4 rv = raw[j] * (cvalid ? 1.0f : 0.0f);
           h16x4 rhi, rlo;
-          mud_split4(rv, rhi, rlo);
+          cm_split4s(raw[j], cvalid ? 1.0f : 0.0f, rhi, rlo);
           char* a2 = smem + G::A2_OFF;
           *(h16x4*)(a2 + loff2[j]) = rhi;
           *(h16x4*)(a2 + (loff2[j] ^ 32)) = rlo;          // unit u -> u ^ 2: the lo half sits two 16-B units away under the same swizzle
@@ -874,21 +906,10 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
-      f32x4 v = raw[j];
-      if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
-        v = v * psc_r + psh_r;
-        if (PRO == MUD_PRO_AFFINE_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = cm_fast_silu(v[e]);
-        }
-      } else if (PRO == MUD_PRO_LRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-      }
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
-      v = v * keep;
       h16x4 hi, lo;
-      mud_split4(v, hi, lo);
+      int a8 = 0, al8 = 0;
+      cm_stage4<PRO, false>(raw[j], psc_r, psh_r, keep, hi, lo, a8, al8);
       *(h16x4*)(buf + loff[j]) = hi;
       *(h16x4*)(buf + loff[j] + 32) = lo;
     }
@@ -1343,6 +1364,10 @@ static int cm_launch(const mud_conv_args& a, hipStream_t s) {
   }
 }
 
+#ifdef MUD_EXPERIMENT_WS
+#include "experiments/conv_ws.inc"
+#endif
+
 // 3x3 tile variant by problem size: big tiles (more MFMA work per weight byte) once they still fill the 256 CUs.
 // Measured on MI355X (scripts/bench_conv.py): MT=2 (two workgroups co-resident per CU, one wave of each per SIMD)
 // beats MT=4 (one workgroup per CU) by 15-40 % on every layer shape; MT=1 only when MT=2 cannot give 2 blocks/CU.
@@ -1449,6 +1474,9 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
               "mud_conv2d_mfma: MUD_PREC_FP8X is not built for this launch (ask mud_conv2d_mfma_prec_supported first; the weights were packed for it and cannot be read by another plan)");
   if (a.B == 0) return MUD_OK;
   hipStream_t s = (hipStream_t)stream;
+#ifdef MUD_EXPERIMENT_WS      // scripts/build_variants.py ws:-DMUD_EXPERIMENT_WS (csrc/experiments/conv_ws.inc); never in the shipped build
+  if (cm_ws_wanted(a)) return cm_ws_dispatch(a, s);
+#endif
   if (a.prec == MUD_PREC_FP8X) {
     const int v8 = cm_variant3(a, nullptr);
     if (v8 == CMV_8X1R) return a.pro_mode == MUD_PRO_NONE ? cm_launch_pro<3, 1, 8, 1, MUD_PRO_NONE, false, MUD_PREC_FP8X>(a, s) : cm_launch_pro<3, 1, 8, 1, MUD_PRO_AFFINE_SILU, false, MUD_PREC_FP8X>(a, s);

@@ -26,7 +26,7 @@ sub("  const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixe
 sub("  store_a(kc0, smem + (kc0 & 1) * G::BUF);\n  __syncthreads();", "  store_a(kc0, smem + (kc0 & 1) * G::BUF);\n  __syncthreads();\n  STAMP(1); STAMP(58);")
 sub("    const bool more = kc + 1 < nchunks;\n#pragma unroll\n    for (int g = 0; g < G::NG; ++g) {", "    const bool more = kc + 1 < nchunks;\n    STAMP(2 + kc);\n#pragma unroll\n    for (int g = 0; g < G::NG; ++g) {")
 sub("      __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves",
-    "      if (kc == 2) STAMP(40 + 2 * g);\n      __syncthreads();\n      if (kc == 2) STAMP(41 + 2 * g);")
+    "      if (kc == 2) STAMP(40 + 2 * g);\n      asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");\n      if (kc == 2) STAMP(46 + g);\n      __syncthreads();\n      if (kc == 2) STAMP(41 + 2 * g);")
 sub("  // ---- epilogue: D[row = pixel (reg&3)+8*(reg>>2)+4*hh][col = channel r]", "  STAMP(60); STAMP(59);\n  // ---- epilogue")
 sub("  if (a.stats) {\n    __syncthreads();\n    if (tid < 128 * WN) {", "  STAMP(61);\n  if (a.stats) {\n    __syncthreads();\n    if (tid < 128 * WN) {")
 b = b[:b.rstrip().rfind("}")] + "  STAMP(62);\n}\n\n"

@@ -45,4 +45,7 @@ for H, Cin, Cout, res in [(256, 64, 64, True), (256, 64, 64, False), (128, 128, 
     f = lambda a: f'{np.median(a):8.0f}'
     grp = [int(np.median(st[:, 40 + i] - (st[:, 2 + 2] if i == 0 else st[:, 39 + i]))) for i in range(6)]
     print('   chunk 2: [group MFMAs+staging, barrier wait] x3 =', grp)
+    drain = [int(np.median(st[:, 46 + g] - st[:, 40 + 2 * g])) for g in range(3)]
+    skew = [int(np.median(st[:, 41 + 2 * g] - st[:, 46 + g])) for g in range(3)]
+    print('   of the barrier wait (wave 0): own memory drain (s_waitcnt vmcnt(0) lgkmcnt(0)) =', drain, ' waiting for the other waves =', skew)
     print(f'{H}^2 {Cin}->{Cout} res={int(res)} plan {"fp8x" if kwp else "16x3"}: cycles(median over 64 blocks, 100 MHz counter?) total{f(tot)} prologue{f(pro)} loop{f(loop)} (per chunk{f(chunk)}, {nch} chunks) epilogue{f(epi)} stats+end{f(tail)}')
