@@ -147,6 +147,12 @@ __device__ __forceinline__ float cm_fast_silu(float v) {
 // MFMAs a packed f32 instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32) costs ~4x two plain ones (MI355X_MICROARCH.md, constants
 // table, "price of one filler beside MFMAs"), and hipcc packs every float4 expression and every pair of adjacent scalar ones it can
 // find - so the staging code works on elements and this file is compiled with -fno-slp-vectorize (csrc/Makefile).
+// Saturating converters: with MODE.FP16_OVFL set, v_cvt_pk_f16_f32 clamps to +-65504 instead of producing inf and
+// v_cvt_pk_fp8_f32 to +-448 instead of NaN (scripts/fp16_ovfl_probe.hip, profiles/r03_n_fp16_ovfl_probe.txt) - so the staging code
+// needs no v_med3 clamp per element (12 of its ~62 vector instructions per float4).  Set once per wave at kernel entry; the mode
+// touches only instructions that PRODUCE fp16 / fp8 values, and the kernels have no others.
+__device__ __forceinline__ void cm_saturating_converters() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+
 template <int PRO, bool X8>
 __device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, const f32x4& sh, float keep, h16x4& hi, h16x4& lo, int& a8, int& al8) {
   f32x4 v, l;
@@ -159,7 +165,7 @@ __device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, cons
     } else if (PRO == MUD_PRO_LRELU) {
       x = x > 0.f ? x : 0.2f * x;
     }
-    v[e] = mud_sat_h16(x * keep);              // zero padding stays zero; fp16 pieces saturate instead of overflowing
+    v[e] = x * keep;                           // zero padding stays zero (the fp16 pieces saturate in the converter: cm_saturating_converters)
   }
   hi = __builtin_convertvector(v, h16x4);      // (2 x v_cvt_pk_f16_f32: a conversion, not packed arithmetic)
 #pragma unroll
@@ -168,8 +174,8 @@ __device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, cons
     float t[4], u[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      t[e] = __builtin_amdgcn_fmed3f(v[e] * (float)(1 << CM_X_SA), -448.0f, 448.0f);
-      u[e] = __builtin_amdgcn_fmed3f(l[e] * (float)(1 << CM_X_SAL), -448.0f, 448.0f);
+      t[e] = v[e] * (float)(1 << CM_X_SA);      // (out-of-range values saturate at +-448 in the converter)
+      u[e] = l[e] * (float)(1 << CM_X_SAL);
     }
     a8 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false), true);
     al8 = __builtin_amdgcn_cvt_pk_fp8_f32(u[2], u[3], __builtin_amdgcn_cvt_pk_fp8_f32(u[0], u[1], 0, false), true);
@@ -181,7 +187,7 @@ __device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, cons
 __device__ __forceinline__ void cm_split4s(const f32x4& rw, float keep, h16x4& hi, h16x4& lo) {
   f32x4 v, l;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = mud_sat_h16(rw[e] * keep);
+  for (int e = 0; e < 4; ++e) v[e] = rw[e] * keep;
   hi = __builtin_convertvector(v, h16x4);
 #pragma unroll
   for (int e = 0; e < 4; ++e) l[e] = v[e] - (float)hi[e];
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   using HV4 = h16x4;
   using HV8 = h16x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cm_saturating_converters();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int wm = wave % WM, wn = wave / WM;     // wave grid: WM along pixel rows, WN along 64-channel tiles
 
@@ -819,6 +826,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
                                                        unsigned nblocks) {
   using G = CmGeoRegB<KS, MT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  cm_saturating_converters();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
 
   // ---- XCD-aware bijective remap: consecutive logical ids share an XCD (blocks i, i+8 are co-resident on one XCD)
