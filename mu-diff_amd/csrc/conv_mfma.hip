@@ -171,14 +171,15 @@ __device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, cons
 #pragma unroll
   for (int e = 0; e < 4; ++e) l[e] = v[e] - (float)hi[e];
   if constexpr (X8) {
-    float t[4], u[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      t[e] = v[e] * (float)(1 << CM_X_SA);      // (out-of-range values saturate at +-448 in the converter)
-      u[e] = l[e] * (float)(1 << CM_X_SAL);
-    }
-    a8 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false), true);
-    al8 = __builtin_amdgcn_cvt_pk_fp8_f32(u[2], u[3], __builtin_amdgcn_cvt_pk_fp8_f32(u[0], u[1], 0, false), true);
+    // v_cvt_scalef32_pk_fp8_f32 divides by its power-of-two scale operand on the way (scripts/exp/scalef32_probe.hip: cvt(x / scale)):
+    // the pre-scales of the two images cost no multiply; out-of-range values saturate at +-448 (cm_saturating_converters)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    constexpr float ia = 1.0f / (float)(1 << CM_X_SA), ial = 1.0f / (float)(1 << CM_X_SAL);
+    const s16x2 z = {0, 0};
+    const s16x2 av = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, v[0], v[1], ia, false), v[2], v[3], ia, true);
+    const s16x2 lv = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, l[0], l[1], ial, false), l[2], l[3], ial, true);
+    a8 = __builtin_bit_cast(int, av);
+    al8 = __builtin_bit_cast(int, lv);
   } else {
     lo = __builtin_convertvector(l, h16x4);
   }
