@@ -25,7 +25,7 @@ SURVEY.md section 8(d) item 4, M = 512 there).  `--sweep 1,2,4,8`: runs the stro
 count that fits the visible devices and prints ONE line {n: slices/s} with the CPU baseline beside it.
 
 One JSON line on rank 0, with
-  roofline        the dominant kernel (3x3 implicit-GEMM conv on split-bf16 MFMA): algorithmic FLOPs /
+  roofline        the dominant kernel (3x3 implicit-GEMM conv on split-precision MFMA, both arithmetic plans): algorithmic FLOPs /
                   per-launch HIP-event time, measured in an instrumented pass of the same workload;
   cpu_baseline    the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's cores on
                   a bounded sample (1 slice), rank 0, N=1 only;

@@ -43,7 +43,7 @@ extern "C" {
 #define MUD_PRO_LRELU 3        /* lrelu_0.2(x), no affine      (DownConvBlock of the critic)  */
 
 /* arithmetic plan of one mud_conv2d_mfma launch (mud_conv_args.prec); the weights must have been packed for the same plan */
-#define MUD_PREC_16X3 0        /* every product as hi*hi + hi*lo + lo*hi on the 16-bit MFMA (bf16 pieces): ~2^-17 per product */
+#define MUD_PREC_16X3 0        /* every product as hi*hi + hi*lo + lo*hi on the 16-bit MFMA (fp16 pieces): ~2^-22 per product */
 #define MUD_PREC_FP8X 1        /* hi*hi on the fp16 MFMA + both cross terms on the block-scaled e4m3 MFMA: ~2^-15 per product, */
                                /* 0.78x the matrix cycles; 3x3 launches that fill the chip (mud_conv2d_mfma_prec_supported)     */
 
@@ -170,8 +170,8 @@ typedef struct mud_conv_args {
 int mud_conv2d_direct(const mud_conv_args* a, void* stream);
 
 /* Implicit-GEMM convolution on the matrix cores, ks in {1,3}, stride 1, pad ks/2.
- * fp32 operands are split on the fly into bf16 hi+lo and multiplied as hi*hi + hi*lo + lo*hi with
- * fp32 accumulation (v_mfma_f32_32x32x16_bf16 x3): ~2^-17 relative error per product.
+ * fp32 operands are split on the fly into fp16 hi+lo (saturating at +-65504) and multiplied as hi*hi + hi*lo + lo*hi with
+ * fp32 accumulation (v_mfma_f32_32x32x16_f16 x3): ~2^-22 relative error per product; a.prec selects the cheaper plan.
  * w: packed by mud_pack_weights().  Requires Cin % 4 == 0, ldx % 4 == 0, 16-byte aligned x.
  * For ks == 1 the (H, W) plane is treated as one flat axis of H*W positions (plain GEMM). */
 int64_t mud_packed_weight_bytes(int ks, int Cin, int Cout);
@@ -211,7 +211,7 @@ int mud_minibatch_stddev(const float* x, int B, int64_t hw, int C, int ld, int g
 
 /* ---- fused attention (layerspp.py:118-122): out[b,i,:] = sum_j softmax_j(q_i.k_j * scale) v_j, single head.
  * qkv: [B, N, ld] with q at +0, k at +C, v at +2C (the fused NIN_0|1|2 output); out [B, N, ldo].
- * Flash-style (no N x N matrix in memory), split-bf16 MFMA.  Head dims: see mud_attention_supported().
+ * Flash-style (no N x N matrix in memory), split-fp16 MFMA.  Head dims: see mud_attention_supported().
  * When batch x ceil(N/128) workgroups would leave most CUs idle (single-slice latency case) the keys are split over
  * up to 16 workgroups per query block and merged by a second tiny kernel; that needs `ws` (mud_attention_ws_bytes(),
  * 16-byte aligned).  ws == NULL always runs unsplit. */

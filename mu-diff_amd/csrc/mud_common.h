@@ -71,8 +71,8 @@ __device__ __forceinline__ float mud_act(float v, int act) {
   }
 }
 
-// sigmoid / silu with the hardware exp2 / rcp (each ~1 ulp): for epilogues whose values were produced by split-bf16 MFMAs
-// (2^-17 per product) - the G2 gate convolution evaluates 4e8 sigmoids per batch-16 launch, and expf + a true divide there
+// sigmoid / silu with the hardware exp2 / rcp (each ~1 ulp): for epilogues whose values were produced by split-precision MFMAs
+// (2^-15 .. 2^-22 per product) - the G2 gate convolution evaluates 4e8 sigmoids per batch-16 launch, and expf + a true divide there
 // cost ~25 instructions per element against 5
 __device__ __forceinline__ float mud_act_fast(float v, int act) {
   switch (act) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ float mud_act_fast(float v, int act) {
 }
 
 // v * sigmoid(v) with the hardware exp2 / rcp (each ~1 ulp, ~3e-7 relative overall): used where the value
-// feeds a bf16 hi+lo split (2^-17) or a 16-tap filter, and a full-precision expf + divide would dominate
+// feeds an fp16 hi+lo split or a 16-tap filter, and a full-precision expf + divide would dominate
 __device__ __forceinline__ float mud_fast_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }

@@ -27,7 +27,7 @@ for H, Cin, Cout, ks in shapes:
     for pro in (None, (sc, sh, ops.PRO_AFFINE_SILU)):
         ms = timeit(lambda: ops.conv(x, w, ks, Cout, mfma=True, pro=pro, out=out))
         fl = 2.0 * B * H * H * Cout * Cin * ks * ks
-        print(f'{H:4d}^2 {Cin:4d}->{Cout:4d} k{ks} pro={"silu" if pro else "none"}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF alg  ({3*fl/ms/1e9/2500*100:5.1f}% bf16 peak issued)')
+        print(f'{H:4d}^2 {Cin:4d}->{Cout:4d} k{ks} pro={"silu" if pro else "none"}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF alg  ({3*fl/ms/1e9/2500*100:5.1f}% of the 16-bit MFMA peak issued)')
 # attention-shaped GEMMs
 N, C = 4096, 256
 q = ops.View(torch.randn(B, 1, N, 3 * C, device=dev), B, 1, N, C, 3 * C, 0)

@@ -202,7 +202,7 @@ def test_tail_conv_kernel(B, H, W, Cin, Cout):
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,ks', [(2, 8, 32, 32, 64, 3), (1, 20, 37, 48, 96, 3), (2, 16, 16, 80, 16, 3), (1, 64, 64, 256, 256, 3),
                                               (1, 33, 9, 8, 24, 3), (2, 16, 16, 64, 128, 1), (1, 5, 7, 36, 40, 1), (1, 64, 64, 256, 768, 1)])
-def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
+def test_conv_mfma_split_precision(B, H, W, Cin, Cout, ks):
     ops, *_ = _imports()
     gen = torch.Generator().manual_seed(Cin + 3 * Cout + ks)
     x = torch.randn(B, Cin, H, W, generator=gen)
@@ -212,7 +212,7 @@ def test_conv_mfma_split_bf16(B, H, W, Cin, Cout, ks):
     out = ops.conv(ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), ks, Cout, mfma=True, bias=g(b)).to_nchw()
     err = maxdiff(out, ref)
     fp32_err = maxdiff(F.conv2d(x, w, b, padding=ks // 2), ref)
-    print(f'conv_mfma {B}x{H}x{W} {Cin}->{Cout} k{ks}: split-bf16 err {err:.2e}, torch fp32 err {fp32_err:.2e}')
+    print(f'conv_mfma {B}x{H}x{W} {Cin}->{Cout} k{ks}: split-fp16 err {err:.2e}, torch fp32 err {fp32_err:.2e}')
     assert err < 3e-5
     # fused prologue (AdaGN affine + SiLU), time-embedding bias, residual, rescale, activation
     sc, sh = torch.randn(B, Cin, generator=gen), torch.randn(B, Cin, generator=gen)
@@ -809,7 +809,7 @@ def test_graph_sampler_matches_eager_and_batches():
     eager = S.sample_from_model(coef, g1, conds[0], g2, conds[1], conds[2], 4, x_init, None, cfg, zs=zs, noises=noises)
     gs = S.GraphSampler(coef, g1, g2, cfg, B, 32, 32, DEV)
     graphed = gs.sample(conds[0], conds[1], conds[2], x_init, 4, zs=zs, noises=noises)
-    # fp64 atomics in the GroupNorm statistics make the last bit of a scale order-dependent; the bf16 hi/lo split
+    # fp64 atomics in the GroupNorm statistics make the last bit of a scale order-dependent; the fp16 hi/lo split
     # turns such a 1-ulp input change into a ~2^-17 local change, so two runs agree to ~1e-5, not bitwise
     assert maxdiff(eager, graphed) < 1e-4
     # slices are independent: sample 1 alone == sample 1 inside the batch (data-parallel sharding is exact)
