@@ -31,6 +31,7 @@
 #include "mud_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -83,7 +84,10 @@ struct CmGeo {
   static constexpr int NG = STEPS / GS;                 // B groups per chunk
   static constexpr int GB1 = GS * CM_BSTEP;             // bytes per B group of ONE 64-channel tile (contiguous in the packed weights)
   static constexpr int GB = WN * GB1;                   // bytes per B group of the workgroup (WN tiles)
-  static constexpr int PIECES = GB / 1024;              // 1 KiB DMA pieces per group
+  // DMA pieces of a group, the same number for EVERY wave: its share GB / waves as N4 pieces of 1 KiB (64 lanes x 16 B) + N1 pieces of
+  // 256 B (64 lanes x 4 B) for the remainder (12 KiB over 8 waves = 1 KiB + 2 x 256 B each; the 12-byte form leaves 4-byte holes in LDS)
+  static constexpr int SHARE = GB / (WM * WN), N4 = SHARE / 1024, N1 = (SHARE % 1024) / 256;
+  static_assert(GB % (WM * WN) == 0 && SHARE % 256 == 0 && GB1 % 1024 == 0, "every wave moves the same number of whole pieces");
   static constexpr int A_BYTES = 2 * BUF;
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
   static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
@@ -108,6 +112,12 @@ struct CmGeo {
 };
 
 
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in the body
+template <class F, int... I>
+__device__ __forceinline__ void cm_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void cm_static_for(F&& f) { cm_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __device__ __forceinline__ bool mud_dev_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
@@ -285,6 +295,22 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   }
 
   f32x4 raw[G::NLOAD];
+  // CNT: the activation loads of chunk k+1 (issued at the head of chunk k's group 0, consumed from group 1 on) stay IN FLIGHT across
+  // group 0's barrier.  hipcc cannot do that by itself: with LDS-DMA and ordinary loads both pending its wait-count pass assumes they
+  // return out of order and waits for vmcnt(0) at the first use - i.e. also for the weight DMA it issued a moment ago - and
+  // __syncthreads() drains everything anyway.  So these loads are issued from inline assembly (invisible to that pass) and waited for
+  // by hand: memory operations of a wave retire in order, so "at most N outstanding" with N = the operations issued AFTER them is exact.
+  // Needs a compile-time number of DMA pieces per wave and group (dma_b below) and no second DMA stream (the fused skip conv).
+  constexpr bool CNT = KS == 3 && !DUAL && WM * WN == 8;   // (the 4-wave tiles of small grids would pay 30-40 registers = a wave per SIMD for it)
+  constexpr int DMA_PER_WAVE = G::N4 + G::N1;
+  // (CNT) wait until at most N younger operations are outstanding, i.e. every activation load has landed; uses of raw[] stay behind the wait
+#define CM_RAW_WAIT(N)                                                          \
+  do {                                                                          \
+    if constexpr (CNT) {                                                        \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < G::NLOAD; ++j_) asm volatile("" : "+v"(raw[j_])); \
+    }                                                                           \
+  } while (0)
   f32x4 psc_r = {1.f, 1.f, 1.f, 1.f}, psh_r = {0.f, 0.f, 0.f, 0.f};   // prologue scale/shift of the chunk in `raw`
   const bool gn_fold = (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) && a.gn_sums != nullptr;   // workgroup-uniform
   const float* const gn_sc = (const float*)(smem + G::GN_OFF);
@@ -293,24 +319,29 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
     int c = chunk * G::KCH + q * 4;
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
-    for (int j = 0; j < G::NLOAD; ++j) raw[j] = *(const f32x4*)(xb + goff[j] + c);
+    for (int j = 0; j < G::NLOAD; ++j) {
+#ifdef MUD_WHATIF_NOLOAD
+      const float f = (float)((tid * 37 + j * 11 + chunk * 5 + c) & 255) * (1.0f / 128.0f) - 1.0f;   // TIMING PROBE: no activation loads (wrong results)
+      raw[j] = f32x4{f, -f * 0.7f, f * 0.31f + 0.2f, 0.9f - f};
+#else
+      if constexpr (CNT) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[j]) : "v"(xb + goff[j] + c) : "memory");
+      else raw[j] = *(const f32x4*)(xb + goff[j] + c);
+#endif
+    }
   };
   auto fetch_ss = [&](int chunk) {
     if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
       int c = chunk * G::KCH + q * 4;
       c = c < a.Cin ? c : 0;
-      if (gn_fold) {
-        psc_r = *(const f32x4*)(gn_sc + c);
-        psh_r = *(const f32x4*)(gn_sc + gn_c + c);
-      } else {
-        psc_r = *(const f32x4*)(psc + c);
-        psh_r = *(const f32x4*)(psh + c);
-      }
+      // always from LDS (the caller's arrays are copied there by the prologue when the GroupNorm finalisation is not folded in): as a
+      // choice between an LDS and a global pointer this becomes a FLAT load, which returns out of order - every wait behind it is vmcnt(0)
+      psc_r = *(const f32x4*)(gn_sc + c);
+      psh_r = *(const f32x4*)(gn_sc + gn_c + c);
     }
   };
   auto fetch_a = [&](int chunk) {
-    fetch_raw(chunk);
     fetch_ss(chunk);
+    fetch_raw(chunk);                           // LAST: the NLOAD youngest loads of the wave at group 0's barrier (counted wait there)
   };
   auto store_a_slots = [&](int chunk, char* buf, int j0, int j1) {
     const bool cvalid = chunk * G::KCH + q * 4 < a.Cin;
@@ -320,7 +351,18 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       HV4 hi, lo;
       int a8 = 0, al8 = 0;
+#ifdef MUD_WHATIF_NOSTAGE
+      {   // TIMING PROBE: no staging arithmetic (finite garbage operands, wrong results)
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        const i32x2 hb = {__builtin_bit_cast(int, raw[j][0]) & 0x3bff3bff, __builtin_bit_cast(int, raw[j][1]) & 0x3bff3bff};
+        hi = __builtin_bit_cast(HV4, hb);
+        lo = hi;
+        a8 = __builtin_bit_cast(int, raw[j][2]) & 0x3f3f3f3f;
+        al8 = __builtin_bit_cast(int, raw[j][3]) & 0x3f3f3f3f;
+      }
+#else
       cm_stage4<PRO, X8>(raw[j], psc_r, psh_r, keep, hi, lo, a8, al8);
+#endif
       *(HV4*)(buf + loff[j]) = hi;
       if constexpr (X8) {                       // (loff holds record + 8 q)
         *(int*)(buf + loff[j] + 32 - q * 4) = a8;          // record + 32 + 4 q
@@ -341,23 +383,28 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   };
   auto store_a = [&](int chunk, char* buf) { store_a_slots(chunk, buf, 0, G::NLOAD); };
 
-  // ---- B operand: groups of GS steps are copied global -> LDS by direct-to-LDS loads (no VGPRs, 1 KiB per
-  // wave instruction, each wave moves a quarter of the group) into a 2-slot ring, one group ahead of its use.
-  // The packed layout already is the LDS image (16-B halves pre-swizzled for conflict-free ds_read_b128).
+  // ---- B operand: groups of GS steps are copied global -> LDS by direct-to-LDS loads (no VGPRs) into a 2-slot ring, one group
+  // ahead of its use.  The packed layout already is the LDS image (16-B halves pre-swizzled for conflict-free ds_read_b128).
+  // Every wave moves the SAME number of pieces per group (CmGeo: 1 KiB pieces + 256-byte pieces for the remainder), and the DMA is branch-free: past the slice's last group the last one is fetched
+  // again, into the ring slot nobody reads any more.  So a wave's count of outstanding operations is known at compile time at every
+  // point of the loop (CNT above), and no control flow splits a group's basic block.
   const int total_groups_all = (k16s * G::TAPS + G::GS - 1) / G::GS;
   const int total_groups = (nchunks * G::NG < total_groups_all) ? nchunks * G::NG : total_groups_all;   // nothing is fetched past this slice
   char* const bring = smem + G::B_OFF;
   auto dma_b = [&](int gg) {                    // group gg -> ring slot gg & 1
-    if (gg >= total_groups) return;             // wave-uniform
     char* dst = bring + (gg & 1) * G::GB;
+    gg = gg < total_groups ? gg : total_groups - 1;
 #pragma unroll
-    for (int j = 0; j < (G::PIECES + WM * WN - 1) / (WM * WN); ++j) {
-      const int piece = wave + WM * WN * j;     // wave-uniform 1 KiB piece of the group image [WN tiles][GS steps][hi|lo][2 KiB]
-      if (piece >= G::PIECES) break;
-      const int t64 = piece / (G::GB1 / 1024), within = piece % (G::GB1 / 1024);
-      const char* src = wb + t64 * tile_bytes + (int64_t)gg * G::GB1 + within * 1024 + lane * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    for (int j = 0; j < G::N4; ++j) {
+      const int byte = (wave + WM * WN * j) * 1024;     // wave-uniform piece of the group image [WN tiles][GS steps][hi|lo][2 KiB]; no piece straddles two tiles
+      const char* src = wb + (byte / G::GB1) * tile_bytes + (int64_t)gg * G::GB1 + byte % G::GB1 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < G::N1; ++j) {
+      const int byte = WM * WN * G::N4 * 1024 + (wave + WM * WN * j) * 256;
+      const char* src = wb + (byte / G::GB1) * tile_bytes + (int64_t)gg * G::GB1 + byte % G::GB1 + lane * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + byte), 4, 0, 0);
     }
   };
   const int lane_b = r * 32 + ((hh ^ ((r >> 3) & 1)) << 4);   // this lane's 16 B inside a [32 co][32 B] fragment image
@@ -443,17 +490,29 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
     cm_gn_to_lds(a, b, tid, G::NT, (float*)(smem + G::GN_OFF), gn_c);
     __syncthreads();
+  } else if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
+    float* sc_lds = (float*)(smem + G::GN_OFF);
+    for (int c = tid; c < a.Cin; c += G::NT) {
+      sc_lds[c] = psc[c];
+      sc_lds[gn_c + c] = psh[c];
+    }
+    __syncthreads();
   }
   fetch_ss(kc0);
+  CM_RAW_WAIT(0);
   store_a(kc0, smem + (kc0 & 1) * G::BUF);
   __syncthreads();
 
-  for (int kc = kc0; kc < nchunks; ++kc) {
+  // One chunk of the reduction.  `more` (a further chunk follows: its tile is fetched and staged under this one's MFMAs) is a
+  // COMPILE-TIME flag and the last chunk its own copy of the body: as a run-time condition it put every staging slice into a basic
+  // block of its own - ~45 dependent vector instructions with no MFMA among them, during which the wave feeds the matrix pipe
+  // nothing - and kept hipcc's scheduler from spreading them over the MFMA gaps of the step (each gap hides ~5 vector issues).
+  auto chunk_body = [&](const int kc, auto more_t) {
+    constexpr bool more = decltype(more_t)::value;
     char* cur = smem + (kc & 1) * G::BUF;
     char* nxt = smem + ((kc + 1) & 1) * G::BUF;
-    const bool more = kc + 1 < nchunks;
-#pragma unroll
-    for (int g = 0; g < G::NG; ++g) {
+    cm_static_for<G::NG>([&](auto g_t) {
+      constexpr int g = decltype(g_t)::value;
       const int gg = kc * G::NG + g;
       dma_b(gg + 1);                            // next group's weights stream in under this group's MFMAs
       if (g == 0 && more) fetch_a(kc + 1);
@@ -488,7 +547,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         const int s = (KS == 3) ? 0 : st;
         const int tap = (KS == 3) ? st : 0;
         const int dy = tap / KS, dx = tap % KS;
-        if (kc * G::CH + s < k16s) {
+        if (KS == 3 || kc * G::CH + s < k16s) {      // (3x3: one k16 step per chunk, always inside the slice)
           HV8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
@@ -564,15 +623,25 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),
         // so the conversion VALU work interleaves with matrix work instead of forming one long MFMA-free stretch
         if (more && G::NG > 1 && st >= G::GS) {
+          if (st == G::GS) CM_RAW_WAIT(DMA_PER_WAVE);   // (CNT) only this group's DMA is younger
           constexpr int SPAN = G::STEPS - G::GS;                   // steps available for staging
           const int j0 = ((st - G::GS) * G::NLOAD) / SPAN, j1 = ((st - G::GS + 1) * G::NLOAD) / SPAN;
           store_a_slots(kc + 1, nxt, j0, j1);
         }
       }
       if (G::NG == 1 && more) store_a(kc + 1, nxt);
-      __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
-    }
-  }
+      if constexpr (g == 0 && more && CNT) {
+        // group 0 issued, in this order, the DMA of group gg+1 and then the NLOAD activation loads of chunk kc+1 (not needed before
+        // group 1).  Memory operations of a wave retire in order: waiting until only NLOAD are outstanding guarantees the DMA has
+        // landed and leaves the activation loads IN FLIGHT across the barrier - __syncthreads() would drain them (HBM latency, ~1-2 us
+        // under load, inside a ~1 us group: with the loads removed the bench line gains 7.6 %).
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::NLOAD) : "memory");
+      } else
+        __syncthreads();                          // DMA of group gg+1 landed (vmcnt drained by the fence) and is visible to all waves
+    });
+  };
+  for (int kc = kc0; kc + 1 < nchunks; ++kc) chunk_body(kc, std::true_type{});
+  if (kc0 < nchunks) chunk_body(nchunks - 1, std::false_type{});
 
   if constexpr (KS == 3) {
     if (slab_mode) {
@@ -1307,7 +1376,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
     attr_once.ok();
   }
   const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN * WN);
-  const int lds = G::lds_bytes(a.gn_sums ? a.Cin : 0);
+  const int lds = G::lds_bytes((KS == 3 ? (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) : a.gn_sums != nullptr) ? a.Cin : 0);   // scale | shift arrays of the sample (3x3: always in LDS)
   int tiles_x = 1;
   int64_t tiles;
   if (KS == 3) {
@@ -1466,6 +1535,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
     a.gn_sums = nullptr;
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),
                 "mud_conv2d_mfma: prologue arrays missing or misaligned");
+    MUD_REQUIRE(a.ks != 3 || a.Cin <= CM_GN_MAXC, "mud_conv2d_mfma: a 3x3 launch with prologue arrays takes Cin <= %d (the kernel keeps them in LDS; Cin=%d)", CM_GN_MAXC, a.Cin);
   } else {
     a.pro_scale = a.pro_shift = a.x;   // never dereferenced
     a.pro_ld = 0;
