@@ -96,6 +96,7 @@ struct CmGeo {
   // and one slot for the 1x1 weights of the current chunk.  The GroupNorm arrays shrink to 512 channels to make room.
   static constexpr int GN_MAXC = DUAL ? 512 : CM_GN_MAXC;
   static constexpr int A2_OFF = A_BYTES + 2 * GB;
+  static_assert(!DUAL || A2_OFF % 64 == 0, "the raw image's hi / lo halves are addressed by flipping bit 5 of the offset");
   static constexpr int A2_BYTES = DUAL ? ROWS * 32 * 64 : 0;
   static constexpr int B2_OFF = A2_OFF + A2_BYTES;
   static constexpr int B2_BYTES = DUAL ? WN * CM_BSTEP : 0;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   // __syncthreads() drains everything anyway.  So these loads are issued from inline assembly (invisible to that pass) and waited for
   // by hand: memory operations of a wave retire in order, so "at most N outstanding" with N = the operations issued AFTER them is exact.
   // Needs a compile-time number of DMA pieces per wave and group (dma_b below) and no second DMA stream (the fused skip conv).
-  constexpr bool CNT = KS == 3 && !DUAL && WM * WN == 8;   // (the 4-wave tiles of small grids would pay 30-40 registers = a wave per SIMD for it)
+  constexpr bool CNT = KS == 3 && !DUAL;        // (the fused-skip kernels sit at 250+ registers: measured 2-5 % slower with it)
   constexpr int DMA_PER_WAVE = G::N4 + G::N1;
   // (CNT) wait until at most N younger operations are outstanding, i.e. every activation load has landed; uses of raw[] stay behind the wait
 #define CM_RAW_WAIT(N)                                                          \
@@ -529,9 +530,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const char* a2 = smem + G::A2_OFF + lane_a2 + m * (32 * 64);
-          const h16x8 ah = *(const h16x8*)a2;
-          const h16x8 al = *(const h16x8*)((const char*)((uintptr_t)a2 ^ 32));
+          // (the lo half sits two 16-B units away under the swizzle: bit 5 of the OFFSET - A2_OFF is a multiple of 64.  Flipping the bit on
+          // the pointer through uintptr_t loses the LDS address space: a FLAT load, and behind it hipcc waits vmcnt(0) lgkmcnt(0), i.e. for
+          // the weight DMA and the activation loads issued a moment ago, at the head of every chunk)
+          const int o2 = lane_a2 + m * (32 * 64);
+          const h16x8 ah = *(const h16x8*)(smem + G::A2_OFF + o2);
+          const h16x8 al = *(const h16x8*)(smem + G::A2_OFF + (o2 ^ 32));
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
             acc2[m][n] = mud_mfma16(al, bh[n], acc2[m][n]);
@@ -625,7 +629,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         if (more && G::NG > 1 && st >= G::GS) {
           if (st == G::GS) CM_RAW_WAIT(DMA_PER_WAVE);   // (CNT) only this group's DMA is younger
           constexpr int SPAN = G::STEPS - G::GS;                   // steps available for staging
-          const int j0 = ((st - G::GS) * G::NLOAD) / SPAN, j1 = ((st - G::GS + 1) * G::NLOAD) / SPAN;
+          // slot boundaries of the staging steps.  Without prologue arithmetic (PRO_NONE: G2's gate / fusion convolutions) a slice is short, and
+          // placing the slices one step LATER (3 slots: steps 5, 7, 8 instead of 4, 6, 8) gives the loads more time: 2-5 % on those launches;
+          // with the AdaGN + SiLU prologue the later placement crowds the end of the group (+0.5-1.5 %: profiles/r03_q_staging_one_step_later.txt)
+          auto jb = [](int i) {
+            if (PRO != MUD_PRO_NONE) return (i * G::NLOAD) / SPAN;
+            return i >= SPAN ? G::NLOAD : ((i > 0 ? i - 1 : 0) * G::NLOAD + G::NLOAD - 1) / SPAN;
+          };
+          const int j0 = jb(st - G::GS), j1 = jb(st - G::GS + 1);
           store_a_slots(kc + 1, nxt, j0, j1);
         }
       }
@@ -967,13 +978,8 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
     if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
       int c = chunk * G::KCH + q * 4;
       c = c < a.Cin ? c : 0;
-      if (gn_fold) {
-        psc_r = *(const f32x4*)(gn_sc + c);
-        psh_r = *(const f32x4*)(gn_sc + gn_c + c);
-      } else {
-        psc_r = *(const f32x4*)(psc + c);
-        psh_r = *(const f32x4*)(psh + c);
-      }
+      psc_r = *(const f32x4*)(gn_sc + c);         // always from LDS (see k_conv_mfma: a choice of pointers here is a FLAT load)
+      psh_r = *(const f32x4*)(gn_sc + gn_c + c);
     }
   };
   auto fetch_a = [&](int chunk) {
@@ -1021,6 +1027,13 @@ __global__ __launch_bounds__(256, (MT == 4 ? 1 : 2)) void k_conv_mfma_regb(mud_c
   for (int s = 0; s < G::RING - 1; ++s) fetch_b(s, s);
   if (gn_fold) {                                // scale / shift of this sample -> LDS while the first loads are in flight
     cm_gn_to_lds(a, b, tid, 256, (float*)(smem + G::GN_OFF), gn_c);
+    __syncthreads();
+  } else if (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) {
+    float* sc_lds = (float*)(smem + G::GN_OFF);
+    for (int c = tid; c < a.Cin; c += 256) {
+      sc_lds[c] = psc[c];
+      sc_lds[gn_c + c] = psh[c];
+    }
     __syncthreads();
   }
   fetch_ss(0);
@@ -1376,7 +1389,7 @@ static int cm_launch_pro(const mud_conv_args& a, hipStream_t s) {
     attr_once.ok();
   }
   const int k16s = (int)mud_cdiv(a.Cin, 16), ntiles = (int)mud_cdiv(a.Cout, CM_BN * WN);
-  const int lds = G::lds_bytes((KS == 3 ? (PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) : a.gn_sums != nullptr) ? a.Cin : 0);   // scale | shift arrays of the sample (3x3: always in LDS)
+  const int lds = G::lds_bytes((PRO == MUD_PRO_AFFINE || PRO == MUD_PRO_AFFINE_SILU) ? a.Cin : 0);   // scale | shift arrays of the sample: always in LDS
   int tiles_x = 1;
   int64_t tiles;
   if (KS == 3) {
@@ -1535,7 +1548,7 @@ extern "C" int mud_conv2d_mfma(const mud_conv_args* ap, void* stream) {
     a.gn_sums = nullptr;
     MUD_REQUIRE(a.pro_scale && a.pro_shift && a.pro_ld >= a.Cin && a.pro_ld % 4 == 0 && mud_aligned16(a.pro_scale) && mud_aligned16(a.pro_shift),
                 "mud_conv2d_mfma: prologue arrays missing or misaligned");
-    MUD_REQUIRE(a.ks != 3 || a.Cin <= CM_GN_MAXC, "mud_conv2d_mfma: a 3x3 launch with prologue arrays takes Cin <= %d (the kernel keeps them in LDS; Cin=%d)", CM_GN_MAXC, a.Cin);
+    MUD_REQUIRE(a.Cin <= CM_GN_MAXC, "mud_conv2d_mfma: a launch with prologue arrays takes Cin <= %d (the kernels keep them in LDS; Cin=%d)", CM_GN_MAXC, a.Cin);
   } else {
     a.pro_scale = a.pro_shift = a.x;   // never dereferenced
     a.pro_ld = 0;
