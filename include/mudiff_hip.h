@@ -121,6 +121,8 @@ typedef struct mud_conv_args {
                                                  /* between per-sample weight sets, 0 = shared       */
   int ks, stride, pad;                           /* square kernel                                    */
   const float* pro_scale; const float* pro_shift; int pro_ld; int pro_mode;   /* [B,Cin] each        */
+                                                 /* (mud_conv2d_mfma keeps them in LDS: Cin <= 1024  */
+                                                 /* with pro_mode AFFINE / AFFINE_SILU)               */
   const float* bias;                             /* [Cout] or NULL                                   */
   const float* bias2; int bias2_ld;              /* [B,Cout] or NULL  (Dense_0(act(temb)))           */
   const float* res; int ldr;                     /* residual view [B,Ho,Wo,Cout] or NULL             */

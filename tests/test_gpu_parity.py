@@ -306,6 +306,25 @@ def test_c_abi_refuses_a_plan_that_is_not_built_for_the_launch():
     assert lib.mud_pack_weights_prec(C.c_void_p(w1.data_ptr()), 0, 64, 1, 0, 1, 64, 64, 1, 1, 0, C.c_void_p(dst.data_ptr()), None) != 0    # ks == 1 has no fp8x form
 
 
+def test_c_abi_refuses_prologue_arrays_wider_than_its_lds_image():
+    """mud_conv2d_mfma keeps the prologue scale / shift of a sample in LDS (2 x 1024 floats): a launch with more input channels
+    and pro_mode AFFINE / AFFINE_SILU must fail loudly, not read past the image; 1024 channels still run and match fp64."""
+    import mudiff_hip
+    ops, *_ = _imports()
+    gen = torch.Generator().manual_seed(7)
+    for Cin, ok in ((1024, True), (1028, False)):
+        x = torch.randn(1, Cin, 8, 8, generator=gen)
+        w = torch.randn(8, Cin, 1, 1, generator=gen) / math.sqrt(Cin)
+        sc, sh = torch.rand(1, Cin, generator=gen) + 0.5, torch.randn(1, Cin, generator=gen)
+        run = lambda: ops.conv(ops.View.from_nchw(g(x)), ops.pack_conv_weight(g(w)), 1, 8, mfma=True, pro=(g(sc), g(sh), ops.PRO_AFFINE))
+        if ok:
+            ref = torch.nn.functional.conv2d((x * sc[:, :, None, None] + sh[:, :, None, None]).double(), w.double())
+            assert float((run().to_nchw().cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+        else:
+            with pytest.raises(mudiff_hip.MudiffHipError, match='Cin <= 1024'):
+                run()
+
+
 @pytest.mark.parametrize('mfma,Cin,Cout,H,W', [(True, 32, 96, 20, 37), (True, 64, 64, 64, 64), (False, 1, 64, 31, 17), (False, 8, 24, 16, 16)])
 def test_epilogue_statistics_equal_two_pass_groupnorm(mfma, Cin, Cout, H, W):
     """A producer's epilogue accumulates per-channel (sum, sumsq) of what it stores; GroupNorm from those
