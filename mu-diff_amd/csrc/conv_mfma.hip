@@ -84,10 +84,11 @@ struct CmGeo {
   static constexpr int NG = STEPS / GS;                 // B groups per chunk
   static constexpr int GB1 = GS * CM_BSTEP;             // bytes per B group of ONE 64-channel tile (contiguous in the packed weights)
   static constexpr int GB = WN * GB1;                   // bytes per B group of the workgroup (WN tiles)
-  // DMA pieces of a group, the same number for EVERY wave: its share GB / waves as N4 pieces of 1 KiB (64 lanes x 16 B) + N1 pieces of
-  // 256 B (64 lanes x 4 B) for the remainder (12 KiB over 8 waves = 1 KiB + 2 x 256 B each; the 12-byte form leaves 4-byte holes in LDS)
-  static constexpr int SHARE = GB / (WM * WN), N4 = SHARE / 1024, N1 = (SHARE % 1024) / 256;
-  static_assert(GB % (WM * WN) == 0 && SHARE % 256 == 0 && GB1 % 1024 == 0, "every wave moves the same number of whole pieces");
+  // DMA pieces of a group (1 KiB = 64 lanes x 16 B each): N4 per wave, and the first REM waves one more (12 KiB over 8 waves: 2 | 1.
+  // Measured against equal counts with 256-byte pieces for the remainder - 1 KiB + 2 x 256 B per wave - the fewer instructions win by 2 %
+  // on those tiles; the 12-byte form, 768 B per instruction, leaves a 4-byte hole behind every lane's 12 bytes: scripts/exp/dma_x3_probe.hip)
+  static constexpr int N4 = GB / (1024 * WM * WN), REM = GB / 1024 - N4 * WM * WN;
+  static_assert(GB % 1024 == 0 && GB1 % 1024 == 0, "whole 1 KiB pieces, none straddling two tiles");
   static constexpr int A_BYTES = 2 * BUF;
   static constexpr int B_OFF = A_BYTES;                 // B ring: 2 groups
   static constexpr int EP_BYTES = WM * WN * (32 * 36 * 4 + 64 * 2 * 4);   // epilogue patches + statistics
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
   // by hand: memory operations of a wave retire in order, so "at most N outstanding" with N = the operations issued AFTER them is exact.
   // Needs a compile-time number of DMA pieces per wave and group (dma_b below) and no second DMA stream (the fused skip conv).
   constexpr bool CNT = KS == 3 && !DUAL;        // (the fused-skip kernels sit at 250+ registers: measured 2-5 % slower with it)
-  constexpr int DMA_PER_WAVE = G::N4 + G::N1;
   // (CNT) wait until at most N younger operations are outstanding, i.e. every activation load has landed; uses of raw[] stay behind the wait
 #define CM_RAW_WAIT(N)                                                          \
   do {                                                                          \
@@ -386,9 +386,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
 
   // ---- B operand: groups of GS steps are copied global -> LDS by direct-to-LDS loads (no VGPRs) into a 2-slot ring, one group
   // ahead of its use.  The packed layout already is the LDS image (16-B halves pre-swizzled for conflict-free ds_read_b128).
-  // Every wave moves the SAME number of pieces per group (CmGeo: 1 KiB pieces + 256-byte pieces for the remainder), and the DMA is branch-free: past the slice's last group the last one is fetched
-  // again, into the ring slot nobody reads any more.  So a wave's count of outstanding operations is known at compile time at every
-  // point of the loop (CNT above), and no control flow splits a group's basic block.
+  // The number of pieces a wave moves per group is a compile-time fact (CmGeo: N4, one more in the first REM waves) and there is no
+  // branch on the group index: past the slice's last group the last one is fetched again, into the ring slot nobody reads any
+  // more.  So a wave's count of outstanding operations is known at every point of the loop (CNT above).
   const int total_groups_all = (k16s * G::TAPS + G::GS - 1) / G::GS;
   const int total_groups = (nchunks * G::NG < total_groups_all) ? nchunks * G::NG : total_groups_all;   // nothing is fetched past this slice
   char* const bring = smem + G::B_OFF;
@@ -401,11 +401,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       const char* src = wb + (byte / G::GB1) * tile_bytes + (int64_t)gg * G::GB1 + byte % G::GB1 + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < G::N1; ++j) {
-      const int byte = WM * WN * G::N4 * 1024 + (wave + WM * WN * j) * 256;
-      const char* src = wb + (byte / G::GB1) * tile_bytes + (int64_t)gg * G::GB1 + byte % G::GB1 + lane * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + byte), 4, 0, 0);
+    if constexpr (G::REM > 0) {                 // the remaining REM KiB: one more piece for the first REM waves (a wave-uniform branch)
+      const int byte = (wave + WM * WN * G::N4) * 1024;
+      if (__builtin_amdgcn_readfirstlane(wave) < G::REM) {
+        const char* src = wb + (byte / G::GB1) * tile_bytes + (int64_t)gg * G::GB1 + byte % G::GB1 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
+      }
     }
   };
   const int lane_b = r * 32 + ((hh ^ ((r >> 3) & 1)) << 4);   // this lane's 16 B inside a [32 co][32 B] fragment image
@@ -627,7 +628,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
         // chunk k+1's LDS image is written slot by slot behind the MFMAs of steps GS.. (its raw loads had group 0 to land),
         // so the conversion VALU work interleaves with matrix work instead of forming one long MFMA-free stretch
         if (more && G::NG > 1 && st >= G::GS) {
-          if (st == G::GS) CM_RAW_WAIT(DMA_PER_WAVE);   // (CNT) only this group's DMA is younger
+          if (st == G::GS) {                    // (CNT) only this group's DMA is younger: N4 pieces, one more in the first REM waves
+            if constexpr (G::REM > 0) {
+              if (__builtin_amdgcn_readfirstlane(wave) < G::REM) CM_RAW_WAIT(G::N4 + 1);
+              else CM_RAW_WAIT(G::N4);
+            } else CM_RAW_WAIT(G::N4);
+          }
           constexpr int SPAN = G::STEPS - G::GS;                   // steps available for staging
           // slot boundaries of the staging steps.  Without prologue arithmetic (PRO_NONE: G2's gate / fusion convolutions) a slice is short, and
           // placing the slices one step LATER (3 slots: steps 5, 7, 8 instead of 4, 6, 8) gives the loads more time: 2-5 % on those launches;
