@@ -86,7 +86,7 @@ struct CmGeo {
   static constexpr int GB = WN * GB1;                   // bytes per B group of the workgroup (WN tiles)
   // DMA pieces of a group (1 KiB = 64 lanes x 16 B each): N4 per wave, and the first REM waves one more (12 KiB over 8 waves: 2 | 1.
   // Measured against equal counts with 256-byte pieces for the remainder - 1 KiB + 2 x 256 B per wave - the fewer instructions win by 2 %
-  // on those tiles; the 12-byte form, 768 B per instruction, leaves a 4-byte hole behind every lane's 12 bytes: scripts/exp/dma_x3_probe.hip)
+  // on those tiles; the 12-byte form, 768 B per instruction, leaves a 4-byte hole behind every lane's 12 bytes: scripts/dma_x3_probe.hip)
   static constexpr int N4 = GB / (1024 * WM * WN), REM = GB / 1024 - N4 * WM * WN;
   static_assert(GB % 1024 == 0 && GB1 % 1024 == 0, "whole 1 KiB pieces, none straddling two tiles");
   static constexpr int A_BYTES = 2 * BUF;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void cm_stage4(const f32x4& rw, const f32x4& sc, cons
 #pragma unroll
   for (int e = 0; e < 4; ++e) l[e] = v[e] - (float)hi[e];
   if constexpr (X8) {
-    // v_cvt_scalef32_pk_fp8_f32 divides by its power-of-two scale operand on the way (scripts/exp/scalef32_probe.hip: cvt(x / scale)):
+    // v_cvt_scalef32_pk_fp8_f32 divides by its power-of-two scale operand on the way (scripts/scalef32_probe.hip: cvt(x / scale)):
     // the pre-scales of the two images cost no multiply; out-of-range values saturate at +-448 (cm_saturating_converters)
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     constexpr float ia = 1.0f / (float)(1 << CM_X_SA), ial = 1.0f / (float)(1 << CM_X_SAL);
@@ -321,13 +321,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
     c = c < a.Cin ? c : 0;                      // clamped; zeroed in store_a
 #pragma unroll
     for (int j = 0; j < G::NLOAD; ++j) {
-#ifdef MUD_WHATIF_NOLOAD
-      const float f = (float)((tid * 37 + j * 11 + chunk * 5 + c) & 255) * (1.0f / 128.0f) - 1.0f;   // TIMING PROBE: no activation loads (wrong results)
-      raw[j] = f32x4{f, -f * 0.7f, f * 0.31f + 0.2f, 0.9f - f};
-#else
       if constexpr (CNT) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[j]) : "v"(xb + goff[j] + c) : "memory");
       else raw[j] = *(const f32x4*)(xb + goff[j] + c);
-#endif
     }
   };
   auto fetch_ss = [&](int chunk) {
@@ -352,18 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 1 && WM * WN == 8) ? 4 : 2) vo
       const float keep = (cvalid && ((vmask >> j) & 1u)) ? 1.0f : 0.0f;   // zero padding stays zero
       HV4 hi, lo;
       int a8 = 0, al8 = 0;
-#ifdef MUD_WHATIF_NOSTAGE
-      {   // TIMING PROBE: no staging arithmetic (finite garbage operands, wrong results)
-        typedef int i32x2 __attribute__((ext_vector_type(2)));
-        const i32x2 hb = {__builtin_bit_cast(int, raw[j][0]) & 0x3bff3bff, __builtin_bit_cast(int, raw[j][1]) & 0x3bff3bff};
-        hi = __builtin_bit_cast(HV4, hb);
-        lo = hi;
-        a8 = __builtin_bit_cast(int, raw[j][2]) & 0x3f3f3f3f;
-        al8 = __builtin_bit_cast(int, raw[j][3]) & 0x3f3f3f3f;
-      }
-#else
       cm_stage4<PRO, X8>(raw[j], psc_r, psh_r, keep, hi, lo, a8, al8);
-#endif
       *(HV4*)(buf + loff[j]) = hi;
       if constexpr (X8) {                       // (loff holds record + 8 q)
         *(int*)(buf + loff[j] + 32 - q * 4) = a8;          // record + 32 + 4 q
